@@ -1,0 +1,435 @@
+// In-LDS mixed-radix FFT program (fp64 complex), shared by every FFT pass kernel.
+//
+// One 1-D transform of length L is a list of radix stages executed in place on
+// an LDS-resident array: forward = decimation in frequency (natural order in,
+// digit-reversed positions out), inverse = the exact stage-by-stage inverse
+// (decimation in time, digit-reversed in, natural out, unnormalised).  The
+// digit reversal is undone for free at the LDS<->global boundary (`pos` table),
+// so HBM always holds natural order.
+//
+// Radices 2,3,4,5,7,8,9 have register butterflies; any other prime factor r
+// (<= 1024) runs as a wave-cooperative O(r) butterfly, which is what lets the
+// solver transform on the reference's *exact* pad size P = N + K//2
+// (CalcSol.py:20-21), e.g. 573 = 3*191 or 1121 = 19*59.
+//
+// Everything here is plain C++ that compiles for host and device: the host build
+// (tests/host/fft_emul.cpp) emulates the thread grid to check the indexing
+// against a long-double DFT without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PS_HD __host__ __device__ __forceinline__
+#else
+#define PS_HD inline
+struct double2 {
+  double x, y;
+};
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+#endif
+
+typedef double2 cplx;
+
+#define PS_MAX_STAGES 14
+#define PS_FWD 0
+#define PS_INV 1
+#define PS_MAX_GENERIC_RADIX 1024
+#define PS_GEN_KPL (PS_MAX_GENERIC_RADIX / 64)
+
+struct FftProg {
+  int32_t L, ns;
+  int32_t radix[PS_MAX_STAGES];
+  int32_t n[PS_MAX_STAGES];  // block length entering stage s
+  int32_t m[PS_MAX_STAGES];  // n / radix
+  // row-mode LDS layout: logical index i lives at (i / Lb) * Lbp + i % Lb.
+  // stages [0,sa) have m % Lb == 0 ("leading"), stages [sa,ns) have n <= Lb.
+  int32_t sa, La, Lb, Lbp;
+  int32_t tw_shift, n_lo, n_hi;  // w_L^t = tw_hi[t >> shift] * tw_lo[t & mask]
+  const cplx* tw_lo;             // device
+  const cplx* tw_hi;             // device
+  const uint32_t* pos;           // device: digit-reversed logical position of k
+  const uint32_t* pos_phys;      // device: row-mode physical position of k
+};
+
+// ---------------------------------------------------------------- complex ops
+PS_HD cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+PS_HD cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+PS_HD cplx cmul(cplx a, cplx b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+PS_HD cplx cmulc(cplx a, cplx b) {  // a * conj(b)
+  return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+PS_HD cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+PS_HD cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
+// multiply by -i (forward) or +i (inverse)
+template <int DIR>
+PS_HD cplx cmul_mi(cplx a) {
+  return DIR == PS_FWD ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+}
+
+// ------------------------------------------------------------ register DFTs
+// All butterflies compute y_k = sum_q x_q w^(qk), w = exp(-+2 pi i / R).
+
+template <int DIR>
+PS_HD void bfly2(cplx* x) {
+  cplx a = x[0], b = x[1];
+  x[0] = cadd(a, b);
+  x[1] = csub(a, b);
+}
+
+template <int DIR>
+PS_HD void bfly4(cplx* x) {
+  cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]);
+  cplx c = cadd(x[1], x[3]), d = cmul_mi<DIR>(csub(x[1], x[3]));
+  x[0] = cadd(a, c);
+  x[2] = csub(a, c);
+  x[1] = cadd(b, d);
+  x[3] = csub(b, d);
+}
+
+// odd prime R with the symmetric form: a_q = x_q + x_{R-q}, b_q = x_q - x_{R-q}
+template <int R>
+struct OddTab;
+template <>
+struct OddTab<3> {
+  static PS_HD double c(int t) {
+    const double v[3] = {1.0, -0.5, -0.5};
+    return v[t];
+  }
+  static PS_HD double s(int t) {
+    const double v[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
+    return v[t];
+  }
+};
+template <>
+struct OddTab<5> {
+  static PS_HD double c(int t) {
+    const double v[5] = {1.0, 0.30901699437494742410, -0.80901699437494742410,
+                         -0.80901699437494742410, 0.30901699437494742410};
+    return v[t];
+  }
+  static PS_HD double s(int t) {
+    const double v[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917,
+                         -0.58778525229247312917, -0.95105651629515357212};
+    return v[t];
+  }
+};
+template <>
+struct OddTab<7> {
+  static PS_HD double c(int t) {
+    const double v[7] = {1.0,
+                         0.62348980185873353053,
+                         -0.22252093395631440429,
+                         -0.90096886790241912624,
+                         -0.90096886790241912624,
+                         -0.22252093395631440429,
+                         0.62348980185873353053};
+    return v[t];
+  }
+  static PS_HD double s(int t) {
+    const double v[7] = {0.0,
+                         0.78183148246802980871,
+                         0.97492791218182360702,
+                         0.43388373911755812048,
+                         -0.43388373911755812048,
+                         -0.97492791218182360702,
+                         -0.78183148246802980871};
+    return v[t];
+  }
+};
+
+template <int R, int DIR>
+PS_HD void bfly_odd(cplx* x) {
+  constexpr int Hh = (R - 1) / 2;
+  cplx a[Hh], b[Hh];
+#pragma unroll
+  for (int q = 1; q <= Hh; ++q) {
+    a[q - 1] = cadd(x[q], x[R - q]);
+    b[q - 1] = csub(x[q], x[R - q]);
+  }
+  cplx x0 = x[0];
+  cplx y0 = x0;
+#pragma unroll
+  for (int q = 0; q < Hh; ++q) y0 = cadd(y0, a[q]);
+  x[0] = y0;
+#pragma unroll
+  for (int k = 1; k <= Hh; ++k) {
+    cplx c = x0, d = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 1; q <= Hh; ++q) {
+      const int t = (q * k) % R;
+      const double ct = OddTab<R>::c(t), st = OddTab<R>::s(t);
+      c.x += a[q - 1].x * ct;
+      c.y += a[q - 1].y * ct;
+      d.x += b[q - 1].x * st;
+      d.y += b[q - 1].y * st;
+    }
+    cplx id = cmul_mi<DIR>(d);  // -i d (fwd), +i d (inv)
+    x[k] = cadd(c, id);
+    x[R - k] = csub(c, id);
+  }
+}
+
+template <int DIR>
+PS_HD void bfly8(cplx* x) {
+  // even / odd DFT-4 then radix-2 combine with w8^k
+  cplx e[4] = {x[0], x[2], x[4], x[6]};
+  cplx o[4] = {x[1], x[3], x[5], x[7]};
+  bfly4<DIR>(e);
+  bfly4<DIR>(o);
+  const double h = 0.70710678118654752440;
+  // w8^1 = (h, -+h), w8^2 = -+i, w8^3 = (-h, -+h)
+  cplx t1 = DIR == PS_FWD ? make_double2((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h)
+                          : make_double2((o[1].x - o[1].y) * h, (o[1].y + o[1].x) * h);
+  cplx t2 = cmul_mi<DIR>(o[2]);
+  cplx t3 = DIR == PS_FWD ? make_double2((o[3].y - o[3].x) * h, -(o[3].x + o[3].y) * h)
+                          : make_double2(-(o[3].x + o[3].y) * h, (o[3].x - o[3].y) * h);
+  x[0] = cadd(e[0], o[0]);
+  x[4] = csub(e[0], o[0]);
+  x[1] = cadd(e[1], t1);
+  x[5] = csub(e[1], t1);
+  x[2] = cadd(e[2], t2);
+  x[6] = csub(e[2], t2);
+  x[3] = cadd(e[3], t3);
+  x[7] = csub(e[3], t3);
+}
+
+template <int DIR>
+PS_HD void bfly9(cplx* x) {
+  // q = q0 + 3 q1 ; y_{k1 + 3 k0} = sum_q0 w9^(q0 k1) (sum_q1 x w3^(q1 k1)) w3^(q0 k0)
+  const double c1 = 0.76604444311897803520, s1 = 0.64278760968653932632;   // 2pi/9
+  const double c2 = 0.17364817766693034885, s2 = 0.98480775301220805937;   // 4pi/9
+  const double c4 = -0.93969262078590838405, s4 = 0.34202014332566873304;  // 8pi/9
+  cplx u[3][3];
+#pragma unroll
+  for (int q0 = 0; q0 < 3; ++q0) {
+    cplx t[3] = {x[q0], x[q0 + 3], x[q0 + 6]};
+    bfly_odd<3, DIR>(t);
+    u[q0][0] = t[0];
+    u[q0][1] = t[1];
+    u[q0][2] = t[2];
+  }
+  const double sg = DIR == PS_FWD ? -1.0 : 1.0;
+  u[1][1] = cmul(u[1][1], make_double2(c1, sg * s1));
+  u[1][2] = cmul(u[1][2], make_double2(c2, sg * s2));
+  u[2][1] = cmul(u[2][1], make_double2(c2, sg * s2));
+  u[2][2] = cmul(u[2][2], make_double2(c4, sg * s4));
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    cplx t[3] = {u[0][k1], u[1][k1], u[2][k1]};
+    bfly_odd<3, DIR>(t);
+    x[k1] = t[0];
+    x[k1 + 3] = t[1];
+    x[k1 + 6] = t[2];
+  }
+}
+
+template <int R, int DIR>
+PS_HD void bfly(cplx* x) {
+  if (R == 2) bfly2<DIR>(x);
+  else if (R == 3) bfly_odd<3, DIR>(x);
+  else if (R == 4) bfly4<DIR>(x);
+  else if (R == 5) bfly_odd<5, DIR>(x);
+  else if (R == 7) bfly_odd<7, DIR>(x);
+  else if (R == 8) bfly8<DIR>(x);
+  else if (R == 9) bfly9<DIR>(x);
+}
+
+// ------------------------------------------------------------------ twiddles
+// forward twiddle w_L^t (t < L) from the two-level tables (LDS copies).
+PS_HD cplx tw_lookup(const cplx* tlo, const cplx* thi, int shift, int t) {
+  return cmul(thi[t >> shift], tlo[t & ((1 << shift) - 1)]);
+}
+
+// ------------------------------------------------------ butterfly addressing
+// mode COL: LDS holds a [L][W] tile (W = 1 << wsh columns, the batch), FFT along
+//           the rows; lanes run along the batch.
+// mode ROW: LDS holds nb padded rows; lanes run along whichever digit is
+//           contiguous (leading stages) or along the La padded sub-rows
+//           (trailing stages), so both are bank-conflict free.
+#define PS_MODE_COL 0
+#define PS_MODE_ROW 1
+
+struct BfAddr {
+  int addr0, qstride, j;
+};
+
+PS_HD BfAddr bf_decode(const FftProg& P, int s, int mode, int item, int wsh, int bs) {
+  const int n = P.n[s], m = P.m[s];
+  BfAddr a;
+  if (mode == PS_MODE_COL) {
+    const int b = item & ((1 << wsh) - 1);
+    const int bf = item >> wsh;
+    const int j = bf % m, blk = bf / m;
+    a.addr0 = ((blk * n + j) << wsh) + b;
+    a.qstride = m << wsh;
+    a.j = j;
+  } else {
+    const int nbf = P.L / P.radix[s];
+    const int b = item / nbf;
+    const int bf = item - b * nbf;
+    if (s < P.sa) {
+      const int mh = m / P.Lb;
+      const int j_lo = bf % P.Lb;
+      const int t = bf / P.Lb;
+      const int j_hi = t % mh, blk = t / mh;
+      a.addr0 = b * bs + (blk * (n / P.Lb) + j_hi) * P.Lbp + j_lo;
+      a.qstride = mh * P.Lbp;
+      a.j = j_hi * P.Lb + j_lo;
+    } else {
+      const int rho = bf % P.La;
+      const int inner = bf / P.La;
+      const int j = inner % m, sub = inner / m;
+      a.addr0 = b * bs + rho * P.Lbp + sub * n + j;
+      a.qstride = m;
+      a.j = j;
+    }
+  }
+  return a;
+}
+
+// ------------------------------------------------------- register-radix stage
+template <int R, int DIR>
+PS_HD void run_stage_r(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P,
+                       int s, int mode, int nb, int wsh, int bs, int tid, int nthr) {
+  const int nitems = (P.L / R) * nb;
+  const int step = P.L / P.n[s];
+  const bool has_tw = P.m[s] > 1;
+  for (int item = tid; item < nitems; item += nthr) {
+    const BfAddr a = bf_decode(P, s, mode, item, wsh, bs);
+    cplx x[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) x[q] = data[a.addr0 + q * a.qstride];
+    cplx w[R];  // w[k] = w_n^(j k)
+    if (has_tw && a.j != 0) {
+      w[1] = tw_lookup(tlo, thi, P.tw_shift, a.j * step);
+      if (R > 2) w[2] = cmul(w[1], w[1]);
+      if (R > 3) w[3] = cmul(w[2], w[1]);
+      if (R > 4) w[4] = cmul(w[2], w[2]);
+      if (R > 5) w[5] = cmul(w[4], w[1]);
+      if (R > 6) w[6] = cmul(w[3], w[3]);
+      if (R > 7) w[7] = cmul(w[4], w[3]);
+      if (R > 8) w[8] = cmul(w[4], w[4]);
+      if (DIR == PS_INV) {
+#pragma unroll
+        for (int q = 1; q < R; ++q) x[q] = cmulc(x[q], w[q]);
+      }
+    }
+    bfly<R, DIR>(x);
+    if (DIR == PS_FWD && has_tw && a.j != 0) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) x[k] = cmul(x[k], w[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) data[a.addr0 + q * a.qstride] = x[q];
+  }
+}
+
+// ------------------------------------------------ wave-cooperative prime stage
+// A wave owns G = max(1, 64 / r) butterflies at a time; lane computes outputs
+// k = sub-lane + 64 u.  All lanes finish reading the r inputs (uniform q loop)
+// before any lane stores, so the update is in place.  Split in two calls so the
+// host emulation can order "all lanes compute" before "all lanes store".
+struct GenAcc {
+  cplx acc[PS_GEN_KPL];
+  int addr0, qstride, k0, active;
+};
+
+template <int DIR>
+PS_HD void gen_compute(GenAcc& g, const cplx* data, const cplx* tlo, const cplx* thi,
+                       const FftProg& P, int s, int mode, int nb, int wsh, int bs,
+                       int group0, int lane) {
+  const int r = P.radix[s];
+  const int nbutter = (P.L / r) * nb;
+  const int G = r < 64 ? 64 / r : 1;
+  const int kpl = (r + 63) / 64;
+  int sub = 0, k0 = lane;
+  if (r < 64) {
+    sub = lane / r;
+    k0 = lane - sub * r;
+  }
+  const int bid = group0 + sub;
+  g.active = (sub < G) && (bid < nbutter);
+  g.k0 = k0;
+  if (!g.active) return;
+  const BfAddr a = bf_decode(P, s, mode, bid, wsh, bs);
+  g.addr0 = a.addr0;
+  g.qstride = a.qstride;
+  const int step = P.L / P.n[s];
+  const int rstep = P.L / r;
+  int idx[PS_GEN_KPL];
+  for (int u = 0; u < kpl; ++u) {
+    g.acc[u] = make_double2(0.0, 0.0);
+    idx[u] = 0;
+  }
+  for (int q = 0; q < r; ++q) {
+    cplx xq = data[a.addr0 + q * a.qstride];
+    if (DIR == PS_INV && a.j != 0 && q != 0)
+      xq = cmulc(xq, tw_lookup(tlo, thi, P.tw_shift, a.j * q * step));
+    for (int u = 0; u < kpl; ++u) {
+      const int k = k0 + 64 * u;
+      if (k < r) {
+        cplx wr = tw_lookup(tlo, thi, P.tw_shift, idx[u] * rstep);
+        g.acc[u] = cadd(g.acc[u], DIR == PS_FWD ? cmul(xq, wr) : cmulc(xq, wr));
+        idx[u] += k;
+        if (idx[u] >= r) idx[u] -= r;
+      }
+    }
+  }
+  if (DIR == PS_FWD && a.j != 0) {
+    for (int u = 0; u < kpl; ++u) {
+      const int k = k0 + 64 * u;
+      if (k < r && k != 0)
+        g.acc[u] = cmul(g.acc[u], tw_lookup(tlo, thi, P.tw_shift, a.j * k * step));
+    }
+  }
+}
+
+PS_HD void gen_store(const GenAcc& g, cplx* data, int r) {
+  if (!g.active) return;
+  const int kpl = (r + 63) / 64;
+  for (int u = 0; u < kpl; ++u) {
+    const int k = g.k0 + 64 * u;
+    if (k < r) data[g.addr0 + k * g.qstride] = g.acc[u];
+  }
+}
+
+template <int DIR>
+PS_HD void run_stage_generic(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P,
+                             int s, int mode, int nb, int wsh, int bs, int tid, int nthr) {
+  const int r = P.radix[s];
+  const int nbutter = (P.L / r) * nb;
+  const int G = r < 64 ? 64 / r : 1;
+  const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+  for (int g0 = wave * G; g0 < nbutter; g0 += nwaves * G) {
+    GenAcc g;
+    gen_compute<DIR>(g, data, tlo, thi, P, s, mode, nb, wsh, bs, g0, lane);
+    gen_store(g, data, r);
+  }
+}
+
+template <int DIR>
+PS_HD void run_stage(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P, int s,
+                     int mode, int nb, int wsh, int bs, int tid, int nthr) {
+  switch (P.radix[s]) {
+    case 2: run_stage_r<2, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 3: run_stage_r<3, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 4: run_stage_r<4, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 5: run_stage_r<5, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 7: run_stage_r<7, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 8: run_stage_r<8, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 9: run_stage_r<9, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    default: run_stage_generic<DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+  }
+}
+
+// row-mode physical position of logical index i
+PS_HD int row_phys(const FftProg& P, int i) {
+  if (P.Lb == 1) return i;
+  const int hi = i / P.Lb;
+  return hi * P.Lbp + (i - hi * P.Lb);
+}
+// LDS elements one row-mode transform occupies
+PS_HD int row_pitch(const FftProg& P) { return P.La * P.Lbp; }

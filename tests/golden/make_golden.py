@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REFERENCE itself.
+
+Run in the build container only (it imports /root/reference, which does not
+exist on the GPU box):
+
+    python tests/golden/make_golden.py [group ...]     # groups: g1 .. g8
+
+Three harness-side shims, none of which touch the
+reference: (1) scipy 1.15 no longer exposes `scipy.stats.mvn`; the same Genz
+Fortran wrapper lives at `scipy.stats._mvn`, registered here under the old
+name; (2) stdout of `prob_mass` (1440 prints per day) is discarded; (3) the
+reference is run from a scratch cwd with a `data/` symlink.
+
+Fixtures are data only: inputs and the reference's outputs.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+import warnings
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+
+def _shim():
+    import scipy.stats
+    import scipy.stats._mvn as _mvn
+    m = types.ModuleType('scipy.stats.mvn')
+    m.mvnun = _mvn.mvnun
+    sys.modules['scipy.stats.mvn'] = m
+    scipy.stats.mvn = m
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    scratch = '/tmp/parasitoid_golden_cwd'
+    os.makedirs(scratch, exist_ok=True)
+    if not os.path.exists(os.path.join(scratch, 'data')):
+        os.symlink(os.path.join(REF, 'data'), os.path.join(scratch, 'data'))
+    os.chdir(scratch)
+
+
+_shim()
+import CalcSol as CS            # noqa: E402  (the reference)
+import ParasitoidModel as PM    # noqa: E402  (the reference)
+from scipy import sparse        # noqa: E402
+
+warnings.simplefilter('ignore')
+
+# default model parameters, Run.py:68-83
+HP = (1., 1.263, 3.913, 7.302, 2.614, 23.999, 2.350)
+DP = (171.82, 144.58, 0.253)
+DLP = (7.096, 7.260, 0.000)
+MU_R = 1.179
+NPER = 30
+# reference test parameters, tests/test_ParsitoidModel.py:24-56
+HP_T = (1.0, 1.8, 6, 7., 2., 19., 2.)
+DP_T = (4.0, 4.0, 0.)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _pm(args):
+    return quiet(PM.prob_mass, *args)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print('wrote', path, os.path.getsize(path + '.npz') // 1024, 'KiB')
+
+
+def coo_pack(prefix, M, out):
+    M = M.tocoo()
+    out[prefix + '_row'] = M.row.astype(np.int32)
+    out[prefix + '_col'] = M.col.astype(np.int32)
+    out[prefix + '_val'] = M.data.astype(np.float64)
+    out[prefix + '_shape'] = np.array(M.shape, dtype=np.int64)
+
+
+def sample_positions(n, count, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n, size=(count, 2))
+
+
+def summarize(prefix, M, out, pos):
+    """nnz, sum, weighted checksum and sampled entries of a big sparse field."""
+    C = M.tocsr()
+    D = M.tocoo()
+    out[prefix + '_nnz'] = np.int64(D.nnz)
+    out[prefix + '_sum'] = np.float64(D.data.sum())
+    wt = 1.0 + ((D.row.astype(np.int64) * 31 + D.col.astype(np.int64) * 17) % 97)
+    out[prefix + '_wsum'] = np.float64((D.data * wt).sum())
+    out[prefix + '_samp'] = np.asarray(C[pos[:, 0], pos[:, 1]]).ravel()
+
+
+# ---------------------------------------------------------------------------
+
+def g1():
+    """mvnun rectangle probabilities."""
+    rng = np.random.default_rng(1)
+    n = 2400
+    rhos = np.array([0.0, 0.253, -0.253, 0.5, -0.5, 0.9, -0.9, 0.3, 0.75,
+                     0.93, -0.93, 0.99, -0.99, 0.9249, 0.925])
+    low = np.empty((n, 2)); upp = np.empty((n, 2)); mu = np.empty((n, 2))
+    S = np.empty((n, 2, 2)); val = np.empty(n)
+    for i in range(n):
+        sx, sy = rng.uniform(3, 200, 2)
+        rho = rhos[i % len(rhos)] if i % 3 else rng.uniform(-0.999, 0.999)
+        S[i] = PM.Dmat(sx, sy, rho)
+        mu[i] = rng.uniform(-20, 20, 2)
+        width = rng.choice([2.0, 4.8828125, 19.53125, 25.0, 78.125])
+        # centres out to ~7 sigma so tails down to ~1e-12 are covered
+        cx = rng.normal(0, 2.5) * sx
+        cy = rng.normal(0, 2.5) * sy
+        low[i] = (cx - width / 2, cy - width / 2)
+        upp[i] = low[i] + width
+        v, inform = PM.mvn.mvnun(low[i], upp[i], mu[i], S[i])
+        assert inform == 0
+        val[i] = v
+    save('g1_mvnun', low=low, upp=upp, mu=mu, S=S, val=val)
+
+
+def g2():
+    """get_mvn_cdf_values stamps."""
+    out = {}
+    cases = []
+    k = 0
+    for c in (78.125, 25.0, 19.53125):
+        for fx, fy in ((0, 0), (0.5, -0.5), (-0.25, 0.3), (0.49, 0.49)):
+            cases.append((c, (fx * c, fy * c), DP))
+    cases.append((9.765625, (1.0, -2.0), DP))
+    cases.append((25.0, (0., 0.), DLP))
+    cases.append((78.125, (0., 0.), DLP))
+    cases.append((2.0, (0., 0.), (4., 4., 0.5)))
+    cases.append((2.0, (0., 0.), (10., 10., -0.5)))
+    cases.append((25.0, (3., -7.), (120., 90., 0.95)))
+    cases.append((25.0, (3., -7.), (120., 90., -0.8)))
+    for c, mu, dp in cases:
+        mat = PM.get_mvn_cdf_values(c, np.array(mu), PM.Dmat(*dp))
+        out['c%d' % k] = np.array([c, mu[0], mu[1], *dp])
+        out['m%d' % k] = mat
+        k += 1
+    out['n'] = np.int64(k)
+    save('g2_stamps', **out)
+
+
+def g3():
+    """h_flight_prob + wind interpolation (G3, G4)."""
+    out = {}
+    for site, st in (('kalbar', '00:00'), ('carnarvonearl', '00:30')):
+        wd, days = PM.get_wind_data('data/' + site, 30, st)
+        out[site + '_days'] = np.array(days)
+        out[site + '_wind_sum'] = np.array([wd[d].sum(0) for d in days])
+        out[site + '_wind_first'] = wd[days[0]]
+        out[site + '_wind_last'] = wd[days[-1]]
+        out[site + '_wind_mid'] = wd[days[3]]
+        out[site + '_h_def'] = np.array(
+            [PM.h_flight_prob(wd[d], *HP) for d in days[:8]])
+        out[site + '_h_test'] = np.array(
+            [PM.h_flight_prob(wd[d], *HP_T) for d in days[:4]])
+    save('g3_hprob_wind', **out)
+
+
+def g5():
+    """prob_mass COO kernels."""
+    out = {}
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    args = [(d, wd, HP, DP, DLP, MU_R, NPER, 10000.0, 128) for d in days[:6]]
+    args += [(d, wd, HP, DP, DLP, MU_R, NPER, 10000.0, 400) for d in days[:2]]
+    wc, dc = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    args.append((dc[0], wc, HP, DP, DLP, MU_R, NPER, 10000.0, 128, 0.354))
+    # strong advection, small domain: clipped + fully-outside periods
+    args.append((days[1], wd, HP, DP, DLP, 6.0, NPER, 2000.0, 64))
+    # reference-test parameter set, full day and noon release
+    args.append((1, wc, HP_T, DP_T, DP_T, 1, 6, 8000.0, 320))
+    args.append((1, wc, HP_T, DP_T, DP_T, 1, 6, 8000.0, 320, 0.5))
+    with Pool(8) as pool:
+        res = pool.map(_pm, args)
+    names = ['kal128_d%d' % d for d in days[:6]] + \
+            ['kal400_d%d' % d for d in days[:2]] + \
+            ['car128_start', 'kal64_clip', 'test320_full', 'test320_noon']
+    for nm, r in zip(names, res):
+        coo_pack(nm, r, out)
+    # single-period TEST_RUN case, tests/test_ParsitoidModel.py:315-325
+    sing = {1: wc[1][24 * 30, :]}
+    hp1 = (1.0, 1.8, 6, -4., 2., 19., 2.)
+    r = quiet(PM.prob_mass, 1, sing, hp1, DP_T, DP_T, 0.1 / 24, 1, 8000.0, 320)
+    coo_pack('test320_single', r, out)
+    out['test320_single_wind'] = sing[1]
+    save('g5_prob_mass', **out)
+
+
+def _kalbar_pmfs(R, nd):
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    args = [(d, wd, HP, DP, DLP, MU_R, NPER, 10000.0, R) for d in days[:nd]]
+    with Pool(8) as pool:
+        return pool.map(_pm, args), days
+
+
+def _recentre(p, R):
+    off = R - p.shape[0] // 2
+    n = 2 * R + 1
+    return sparse.coo_matrix((p.data, (p.row + off, p.col + off)), shape=(n, n))
+
+
+def _max_shape(pmfs):
+    ms = np.array([0, 0])
+    for p in pmfs:
+        ms = np.maximum(ms, p.shape)
+    return ms
+
+
+def g6():
+    """get_solutions, config 1 (Kalbar, R=128, 6 days) + R=200 flag sequence."""
+    out = {}
+    for R, nd, full in ((128, 6, True), (200, 18, False)):
+        pmfs, days = _kalbar_pmfs(R, nd)
+        N = 2 * R + 1
+        ms = _max_shape(pmfs)
+        tag = 'r%d' % R
+        out[tag + '_max_shape'] = ms
+        out[tag + '_ndays'] = np.int64(nd)
+        for i, p in enumerate(pmfs):
+            coo_pack('%s_pmf%d' % (tag, i), p, out)
+        modelsol = [_recentre(pmfs[0], R)]
+        quiet(CS.get_solutions, modelsol, pmfs, days, nd, N, ms)
+        pos = sample_positions(N, 4000, 7)
+        out[tag + '_pos'] = pos
+        for i, s in enumerate(modelsol):
+            if full:
+                coo_pack('%s_sol%d' % (tag, i), s, out)
+            summarize('%s_sum%d' % (tag, i), s, out, pos)
+        # replay with the reference's own primitives: flags and raw fields
+        hat = CS.fft2(_recentre(pmfs[0], R), ms)
+        flags = []
+        for n in range(1, nd):
+            CS.fftconv2(hat, pmfs[n].tocsr())
+            A, flag = CS.ifft2(hat, [N, N])
+            flags.append(flag)
+            Ad = A.toarray()
+            out['%s_rawsamp%d' % (tag, n)] = Ad[pos[:, 0], pos[:, 1]]
+            out['%s_rawsum%d' % (tag, n)] = np.float64(Ad.sum())
+            out['%s_rawmin%d' % (tag, n)] = np.float64(Ad.min())
+            if flag:
+                hat = CS.fft2(A, ms)
+        out[tag + '_flags'] = np.array(flags)
+    save('g6_solutions', **out)
+
+
+def g7():
+    """get_populations, Kalbar r_dur=1: R=128 6 days (full), R=400 18 days."""
+    out = {}
+    dist = lambda day: 1.0                                      # uniform, r_dur=1
+    for R, nd, full in ((128, 6, True), (400, 18, False)):
+        pmfs, days = _kalbar_pmfs(R, nd)
+        N = 2 * R + 1
+        ms = _max_shape(pmfs)
+        tag = 'r%d' % R
+        out[tag + '_max_shape'] = ms
+        out[tag + '_ndays'] = np.int64(nd)
+        if R == 400:
+            for i, p in enumerate(pmfs):
+                coo_pack('%s_pmf%d' % (tag, i), p, out)
+        r_spread = [_recentre(pmfs[0], R).tocsr()]
+        pop = quiet(CS.get_populations, r_spread, pmfs, days, nd, N, ms,
+                    1, 130000, dist)
+        pos = sample_positions(N, 4000, 11)
+        out[tag + '_pos'] = pos
+        for i, s in enumerate(pop):
+            if full:
+                coo_pack('%s_pop%d' % (tag, i), s, out)
+            summarize('%s_sum%d' % (tag, i), s, out, pos)
+    save('g7_populations', **out)
+
+
+def g8():
+    """back_solve: toy arrays (tests/test_CalcSol.py:41-62, :115-139) and
+    Carnarvon --pop r_dur=5 at domain_info=(40000.0,200), 30 days."""
+    out = {}
+    Ad = np.outer(range(5), np.arange(.1, .6, .1))
+    Bd = np.outer(np.arange(0, 2.5, 0.5), np.ones(5))
+    Cd = np.outer(range(5, 0, -1), np.arange(.1, .6, .1))
+    Dd = np.outer(np.arange(1, 0, -.2), np.arange(0, 2.5, 0.5))
+    mats = []
+    for X in (Ad, Bd, Cd, Dd):
+        Z = np.zeros((55, 55)); Z[25:30, 25:30] = X
+        mats.append(Z)
+    A, B, C, D = mats
+    C_hat = CS.fft2(sparse.coo_matrix(C), A.shape)
+    CS.fftconv2(C_hat, sparse.csr_matrix(D))
+    bck = CS.back_solve([sparse.csr_matrix(A), sparse.csr_matrix(B)],
+                        C_hat, A.shape)
+    out['toy_bck0'] = bck[0].toarray()
+    out['toy_bck1'] = bck[1].toarray()
+    for nm, X in zip('ABCD', mats):
+        out['toy_' + nm] = X
+
+    wc, dc = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    R, nd, r_dur, r_number = 200, 30, 5, 40000
+    args = [(dc[0], wc, HP, DP, DLP, MU_R, NPER, 40000.0, R, 0.354)]
+    args += [(d, wc, HP, DP, DLP, MU_R, NPER, 40000.0, R) for d in dc[1:nd]]
+    with Pool(8) as pool:
+        pmfs = pool.map(_pm, args)
+    N = 2 * R + 1
+    ms = _max_shape(pmfs)
+    out['car_max_shape'] = ms
+    for i, p in enumerate(pmfs):
+        coo_pack('car_pmf%d' % i, p, out)
+    r_spread = [_recentre(pmfs[i], R).tocsr() for i in range(r_dur)]
+    dist = lambda day: 1. / r_dur
+    pop = quiet(CS.get_populations, r_spread, pmfs, dc, nd, N, ms, r_dur,
+                r_number, dist)
+    pos = sample_positions(N, 4000, 13)
+    out['car_pos'] = pos
+    for i, s in enumerate(pop):
+        summarize('car_sum%d' % i, s, out, pos)
+    for i in (0, 4, 5, 29):
+        coo_pack('car_pop%d' % i, pop[i], out)
+    save('g8_back_solve', **out)
+
+
+GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8}
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or list(GROUPS)
+    for g in which:
+        print('==', g)
+        GROUPS[g]()
