@@ -1,0 +1,171 @@
+/* parasitoid_hip.h -- C ABI of libparasitoid_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the drift-diffusion forward solver of
+ * mountaindust/Parasitoids.  Each entry point names the reference interface it
+ * replaces (file:line relative to the reference repository).  Plain pointers and
+ * sizes only; all inputs are caller-owned host buffers that are copied before
+ * the call returns and never modified; outputs go to caller-allocated buffers
+ * sized from a preceding count call (two-phase COO output).
+ *
+ * Every function returns PS_OK (0) or a negative error class; ps_last_error()
+ * gives the message of the last failure on the calling thread.  One handle =
+ * one device + one HIP stream; a handle is not thread-safe, different handles
+ * are independent.  No HIP call is made at library load (fork-safe: the
+ * reference forks a multiprocessing pool before it touches the GPU,
+ * Run.py:422-425, Bayes_Run.py:706).
+ */
+#ifndef PARASITOID_HIP_H
+#define PARASITOID_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_OK 0
+#define PS_ERR_NO_DEVICE (-1)   /* no gfx950 device / HIP runtime unusable          */
+#define PS_ERR_OOM (-2)         /* device allocation failed (cuda_lib.py:31,:72,:108,:159 asserts) */
+#define PS_ERR_BAD_SHAPE (-3)   /* even kernel shape (CalcSol.py:58), kernel larger than the pad, indices out of range */
+#define PS_ERR_BAD_ARG (-4)
+#define PS_ERR_UNSUPPORTED (-5) /* FFT length not plannable (prime factor > 1024 or length > LDS) */
+#define PS_ERR_HIP (-6)         /* HIP runtime error                                 */
+#define PS_ERR_HPROB_BOUNDS (-7)/* ParasitoidModel.py:528-537  hprob out of bounds   */
+#define PS_ERR_PMF_NEGATIVE (-8)/* ParasitoidModel.py:570,:589 pmf.min() < -1e-8     */
+#define PS_ERR_FLIGHT_PROB (-9) /* ParasitoidModel.py:569,:571,:590 flight prob > 1 / negative loss */
+#define PS_ERR_STATE (-10)      /* call order (e.g. fetch before run)                */
+#define PS_ERR_EMPTY (-11)      /* prob_mass produced no entry >= 1e-8               */
+
+#define PS_MODE_EXACT 0 /* FFT on the reference's torus P = N + K//2 (CalcSol.py:20-21) */
+#define PS_MODE_FAST 1  /* FFT on the next even 7-smooth size >= P                       */
+
+typedef struct ps_solver ps_solver;
+typedef struct ps_model ps_model;
+
+typedef struct ps_day_stats {
+  int64_t nnz;   /* entries with value*scale >= negval (r_small_vals, CalcSol.py:126-132) */
+  double sum;    /* their sum                                                            */
+  double delta;  /* (1-sum)/nnz added to every entry when renorm (CalcSol.py:134-135)    */
+  double padmax; /* max over the pad region, clamped at 0 (CalcSol.py:36-37)             */
+  int32_t flag;  /* padmax > 1e-8 -> state was truncated and re-transformed (:38,:200-201) */
+  int32_t pad_;
+} ps_day_stats;
+
+/* ---- library ---------------------------------------------------------------- */
+int ps_version(void);
+int ps_device_count(void);             /* < 0 on error */
+const char* ps_last_error(void);
+/* device properties for reports: name[<=n], CU count, total HBM bytes */
+int ps_device_info(int device, char* name, int n, int* cus, int64_t* hbm_bytes);
+
+/* ---- solver: replaces class cuda_lib.CudaSolve (cuda_lib.py:16-221) and the
+ *      CPU primitives CalcSol.fft2/fftconv2/ifft2/back_solve (CalcSol.py:11-109) */
+
+/* CudaSolve.__init__ shape logic (cuda_lib.py:26-28): pad = dom_len + max_shape//2. */
+int ps_solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode);
+int ps_solver_destroy(ps_solver* s);
+/* P = reference torus, Pfft = transform size in use, H = Pfft/2+1 */
+int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H);
+int ps_solver_sync(ps_solver* s);
+
+/* CudaSolve.__init__ (cuda_lib.py:34-54) / CalcSol.fft2 (CalcSol.py:11-24):
+ * state_hat = FFT2(zero-padded N x N sparse field). */
+int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const int32_t* col,
+                            const double* val, int64_t nnz);
+
+/* CudaSolve.fftconv2 (cuda_lib.py:58-94) / CalcSol.fftconv2 (CalcSol.py:45-66):
+ * wrap the odd kshape x kshape kernel to the origin, FFT, state_hat *= B_hat. */
+int ps_solver_fftconv2_coo(ps_solver* s, const int32_t* row, const int32_t* col,
+                           const double* val, int64_t nnz, int kshape);
+
+/* CudaSolve.get_cursol (cuda_lib.py:98-140) / CalcSol.ifft2 (+ re-FFT, CalcSol.py:28-41,
+ * :200-201): inverse transform, boundary flag, truncate + re-transform when flagged.
+ * The N x N field stays on the device as chain record 0.  Statistics are taken on
+ * value*stat_scale >= negval; renorm != 0 computes the prob-model delta. */
+int ps_solver_get_cursol(ps_solver* s, double negval, double stat_scale, int renorm,
+                         ps_day_stats* stats);
+
+/* CudaSolve.back_solve (cuda_lib.py:145-221) / CalcSol.back_solve (CalcSol.py:72-109):
+ * nfilt N x N filters in chronological order, concatenated COO with offsets
+ * off[nfilt+1].  Results stay on the device as back-solve records 0..nfilt-1 in
+ * emergence order; stats[nfilt] optional. */
+int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off, const int32_t* row,
+                         const int32_t* col, const double* val, double negval,
+                         double stat_scale, ps_day_stats* stats);
+
+/* ---- whole day chain: replaces the loops of CalcSol.get_solutions
+ *      (CalcSol.py:191-201) and CalcSol.get_populations (:308-323, r_dur == 1) ---- */
+
+/* Upload nk day kernels (pmf_list entries, ParasitoidModel.prob_mass output): COO
+ * concatenated with offsets off[nk+1]; kshape[d] odd.  All kernel transforms are
+ * batched up front (they do not depend on the state). */
+int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                         const int32_t* row, const int32_t* col, const double* val);
+/* Run days [first, first+count) from the current state: per day
+ * fftconv2 -> ifft2 -> statistics/flag -> (flagged) truncate + re-FFT, all enqueued on
+ * the handle's stream without host synchronisation.  Day d's field is chain record d. */
+int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_scale,
+                 int renorm);
+int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out); /* synchronises */
+
+/* ---- records (device-resident N x N fields) ----
+ * kind 0: chain/get_cursol records, 1: back_solve records, 2: state (first day),
+ * 3: scratch result of ps_weighted_sum. */
+#define PS_REC_CHAIN 0
+#define PS_REC_BACK 1
+#define PS_REC_STATE 2
+#define PS_REC_WSUM 3
+/* (re)compute statistics of any record with the given threshold/scale */
+int ps_record_stats(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                    int renorm, ps_day_stats* out);
+/* r_small_vals + coo_matrix(dense) order (CalcSol.py:112-136): entries with
+ * v*stat_scale >= negval, row-major; value = (v*stat_scale + delta) * post_scale.
+ * cap must be >= the nnz reported by the matching stats call. */
+int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                        double delta, double post_scale, int32_t* row, int32_t* col,
+                        double* val, int64_t cap, int64_t* nnz_out);
+int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out /* N*N */);
+/* sum_d w[d] * record(kind[d], idx[d]) -> record (PS_REC_WSUM,0)  (CalcSol.py:322) */
+int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx,
+                    const double* w);
+
+/* full P x P complex spectrum in/out (function-level CalcSol.fft2/fftconv2/ifft2 mirrors;
+ * only valid in PS_MODE_EXACT) */
+int ps_solver_get_spectrum(ps_solver* s, double* out /* P*P*2 */);
+int ps_solver_set_spectrum(ps_solver* s, const double* in /* P*P*2 */);
+
+/* ---- per-day kernel construction: replaces ParasitoidModel.prob_mass
+ *      (ParasitoidModel.py:384-613) incl. h_flight_prob (:282-309) and
+ *      get_mvn_cdf_values (:311-380) ---- */
+int ps_model_create(ps_model** out, int device);
+int ps_model_destroy(ps_model* m);
+/* wind: float64 [ndays_wind][T][3] (windx, windy, windr), rows in the order of the
+ * sorted day keys; day_keys[ndays_wind] the integer keys (prob_mass looks up day+1).
+ * T == 1 rows with test_run != 0 reproduce the single-period mode (:422-428). */
+int ps_model_set_wind(ps_model* m, const double* wind, const int32_t* day_keys, int ndays_wind,
+                      int T, int test_run);
+/* Build the kernels of nd days in one batch.  day_idx[i] indexes the wind rows;
+ * start_time[i] < 0 means None.  hparams = (lam,aw,bw,a1,b1,a2,b2), Dparams/Dlparams =
+ * (sig_x,sig_y,rho).  Outputs per day: kshape (odd side of the shrunk kernel), nnz,
+ * warned (1 if a period left the domain, ParasitoidModel.py:549-557), status
+ * (PS_OK or the assertion class that fired). */
+int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, const double* start_time,
+                       const double* hparams, const double* Dparams, const double* Dlparams,
+                       double mu_r, int n_periods, double rad_dist, int rad_res,
+                       int32_t* kshape, int64_t* nnz, int32_t* warned, int32_t* status);
+int ps_model_fetch_coo(ps_model* m, int i, int32_t* row, int32_t* col, double* val, int64_t cap);
+/* diagnostics for tests: hprob[T] of day i of the last batch, stamp half-widths H[T] */
+int ps_model_fetch_debug(ps_model* m, int i, double* hprob, int32_t* Hs, double* loss,
+                         double* pmfsum);
+/* get_mvn_cdf_values (ParasitoidModel.py:311-380) for one (cell, mu, S): returns the
+ * half width; fills out[(2H+1)^2] when cap allows. */
+int ps_model_mvn_cdf_values(ps_model* m, double cell, double mu_x, double mu_y, double sig_x,
+                            double sig_y, double rho, int32_t* H, double* out, int64_t cap);
+/* hand the kernels of the last batch straight to a solver on the same device
+ * (no host round trip): equivalent to ps_chain_set_kernels with days [first, first+count). */
+int ps_chain_set_kernels_from_model(ps_solver* s, ps_model* m, int first, int count);
+int ps_solver_set_state_from_model(ps_solver* s, ps_model* m, int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,172 @@
+// Non-FFT kernels of the day chain: COO scatter (CalcSol.py:23,:61-64), per-day
+// statistics/flag (CalcSol.py:36-40,:126-135), ordered stream compaction back to
+// COO, and the release-day weighted sum of CalcSol.get_populations (:322-323).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// dst[(row+roff)*ld + col+coff] += val   (duplicates sum, as coo.toarray() does)
+__global__ void k_scatter_coo(const int* __restrict__ row, const int* __restrict__ col,
+                              const double* __restrict__ val, int64_t nnz, double* dst, int ld,
+                              int roff, int coff) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nnz;
+       i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&dst[(int64_t)(row[i] + roff) * ld + col[i] + coff], val[i]);
+}
+
+struct DayStats {
+  long long nnz;      // entries with v*scale >= negval
+  double sum;         // their sum
+  double delta;       // (1 - sum)/nnz  (prob model renormalisation), else 0
+  double padmax;      // max over the pad region (>= 0)
+  int flag;           // padmax > 1e-8
+  int pad_;
+};
+
+// one block: reduce per-row statistics of one day in a fixed order
+__global__ void k_day_finalize(const double* rowsum, const long long* rowcnt,
+                               const unsigned long long* padmax, int N, int renorm,
+                               DayStats* out, int* flag_out) {
+  __shared__ double ssum[256];
+  __shared__ long long scnt[256];
+  double s = 0.0;
+  long long c = 0;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    s += rowsum[r];
+    c += rowcnt[r];
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + off];
+      scnt[threadIdx.x] += scnt[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    DayStats d;
+    d.nnz = scnt[0];
+    d.sum = ssum[0];
+    d.delta = (renorm && scnt[0] > 0) ? (1.0 - ssum[0]) / (double)scnt[0] : 0.0;
+    d.padmax = __longlong_as_double((long long)*padmax);
+    d.flag = d.padmax > 1e-8 ? 1 : 0;
+    d.pad_ = 0;
+    *out = d;
+    if (flag_out) *flag_out = d.flag;
+  }
+}
+
+// per-row statistics of a dense N x N field (used when a field was not produced
+// by the fused inverse-row epilogue, e.g. weighted sums and the first day)
+__global__ void k_row_stats(const double* __restrict__ rec, int N, double scale, double negval,
+                            double* rowsum, long long* rowcnt) {
+  __shared__ double ssum[256];
+  __shared__ int scnt[256];
+  const int r = blockIdx.x;
+  double s = 0.0;
+  int c = 0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const double t = rec[(int64_t)r * N + i] * scale;
+    if (t != 0.0 && !(t < negval)) { s += t; ++c; }
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + off];
+      scnt[threadIdx.x] += scnt[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { rowsum[r] = ssum[0]; rowcnt[r] = scnt[0]; }
+}
+
+// exclusive scan of per-row counts (single block, N <= ~16k rows)
+__global__ void k_scan_rows(const long long* rowcnt, int N, long long* rowoff) {
+  __shared__ long long part[1024];
+  const int T = blockDim.x;
+  const int per = (N + T - 1) / T;
+  const int lo = threadIdx.x * per, hi = min(N, lo + per);
+  long long s = 0;
+  for (int r = lo; r < hi; ++r) s += rowcnt[r];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long acc = 0;
+    for (int t = 0; t < T; ++t) { long long v = part[t]; part[t] = acc; acc += v; }
+  }
+  __syncthreads();
+  long long acc = part[threadIdx.x];
+  for (int r = lo; r < hi; ++r) { rowoff[r] = acc; acc += rowcnt[r]; }
+}
+
+// ordered compaction: one wave per row, row-major COO order like coo_matrix(dense)
+__global__ void k_compact_rows(const double* __restrict__ rec, int N, double scale, double negval,
+                               double delta, double post_scale, const long long* rowoff,
+                               int* orow, int* ocol, double* oval) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= N) return;
+  long long base = rowoff[wave];
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int c = c0 + lane;
+    double t = 0.0;
+    bool keep = false;
+    if (c < N) {
+      t = rec[(int64_t)wave * N + c] * scale;
+      keep = (t != 0.0) && !(t < negval);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int o = __popcll(m & ((1ull << lane) - 1ull));
+      orow[base + o] = wave;
+      ocol[base + o] = c;
+      oval[base + o] = (t + delta) * post_scale;
+    }
+    base += __popcll(m);
+  }
+}
+
+// out = sum_d w[d] * rec_d   (release-day weighted population, CalcSol.py:322)
+__global__ void k_weighted_sum(const double* const* recs, const double* w, int nrec, int64_t n,
+                               double* out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int d = 0; d < nrec; ++d) acc += recs[d][i] * w[d];
+    out[i] = acc;
+  }
+}
+
+// Hermitian expansion of the half spectrum to a full P x P complex array
+// (only for the function-level CalcSol.fft2/fftconv2 mirrors)
+__global__ void k_expand_spectrum(const double2* __restrict__ half, int P, int H, int ld,
+                                  double2* full) {
+  const int64_t tot = (int64_t)P * P;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < tot;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / P), c = (int)(idx % P);
+    double2 v;
+    if (c < H) {
+      v = half[(int64_t)r * ld + c];
+    } else {
+      const int rr = r ? P - r : 0, cc = P - c;
+      v = half[(int64_t)rr * ld + cc];
+      v.y = -v.y;
+    }
+    full[idx] = v;
+  }
+}
+
+__global__ void k_take_half_spectrum(const double2* __restrict__ full, int P, int H, int ld,
+                                     double2* half) {
+  const int64_t tot = (int64_t)P * H;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < tot;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / H), c = (int)(idx % H);
+    half[(int64_t)r * ld + c] = full[(int64_t)r * P + c];
+  }
+}

@@ -1,0 +1,99 @@
+// Shared host-side helpers of libparasitoid_hip.so: error reporting, device
+// buffers, uploaded FFT plans.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/parasitoid_hip.h"
+#include "fft_plan.h"
+
+extern thread_local std::string ps_tls_error;
+
+inline int ps_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  ps_tls_error = buf;
+  return code;
+}
+
+#define PS_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      int code_ = (e_ == hipErrorOutOfMemory) ? PS_ERR_OOM : PS_ERR_HIP;                 \
+      return ps_fail(code_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                     __FILE__, __LINE__);                                                \
+    }                                                                                    \
+  } while (0)
+
+#define PS_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != PS_OK) return rc_; \
+  } while (0)
+
+// growable device buffer
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return PS_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e != hipSuccess)
+      return ps_fail(e == hipErrorOutOfMemory ? PS_ERR_OOM : PS_ERR_HIP,
+                     "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    cap = n;
+    return PS_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct DevPlan {
+  HostFftPlan host;
+  FftProg prog;  // with device pointers
+  DevBuf<cplx> tw_lo, tw_hi;
+  DevBuf<uint32_t> pos, pos_phys;
+  bool generic = false;
+  int upload() {
+    prog = host.prog;
+    PS_TRY(tw_lo.ensure(host.tw_lo.size()));
+    PS_TRY(tw_hi.ensure(host.tw_hi.size()));
+    PS_TRY(pos.ensure(host.pos.size()));
+    PS_TRY(pos_phys.ensure(host.pos_phys.size()));
+    PS_HIP(hipMemcpy(tw_lo.p, host.tw_lo.data(), host.tw_lo.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(tw_hi.p, host.tw_hi.data(), host.tw_hi.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(pos.p, host.pos.data(), host.pos.size() * 4, hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(pos_phys.p, host.pos_phys.data(), host.pos_phys.size() * 4, hipMemcpyHostToDevice));
+    prog.tw_lo = tw_lo.p;
+    prog.tw_hi = tw_hi.p;
+    prog.pos = pos.p;
+    prog.pos_phys = pos_phys.p;
+    generic = false;
+    for (int s = 0; s < prog.ns; ++s)
+      if (prog.radix[s] > 9 || prog.radix[s] == 6) generic = true;
+    return PS_OK;
+  }
+  void release() {
+    tw_lo.release();
+    tw_hi.release();
+    pos.release();
+    pos_phys.release();
+  }
+};
+
+int ps_use_device(int device);

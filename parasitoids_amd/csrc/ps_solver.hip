@@ -1,0 +1,756 @@
+// libparasitoid_hip.so -- day-chain FFT convolution solver (C ABI in
+// include/parasitoid_hip.h).  Replaces cuda_lib.CudaSolve (cuda_lib.py:16-221) and
+// the CPU chain of CalcSol.py:140-325 with fp64 HIP kernels for gfx950.
+#include "chain_kernels.h"
+#include "fft_kernels.h"
+#include "ps_common.h"
+
+thread_local std::string ps_tls_error;
+
+extern "C" const char* ps_last_error(void) { return ps_tls_error.c_str(); }
+extern "C" int ps_version(void) { return 100; }
+
+extern "C" int ps_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return ps_fail(PS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+extern "C" int ps_device_info(int device, char* name, int n, int* cus, int64_t* hbm_bytes) {
+  hipDeviceProp_t p;
+  PS_HIP(hipGetDeviceProperties(&p, device));
+  if (name && n > 0) snprintf(name, n, "%s (%s)", p.name, p.gcnArchName);
+  if (cus) *cus = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return PS_OK;
+}
+
+int ps_use_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return ps_fail(PS_ERR_NO_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return ps_fail(PS_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, n);
+  PS_HIP(hipSetDevice(device));
+  return PS_OK;
+}
+
+static const int kMaxLds = 160 * 1024;
+
+struct ColPass {
+  DevPlan* plan;
+  int n_outer, in_base_mul, in_stride, out_base_mul, out_stride, tw_mode;
+};
+
+struct ps_solver {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int N = 0, M = 0, Pref = 0, Pf = 0, H = 0, ld = 0, mode = 0;
+  DevPlan row_plan, col_plan1, col_plan2;
+  bool split = false;
+  int L1 = 0, L2 = 0;
+  DevBuf<cplx> tp_lo, tp_hi;
+  int tp_shift = 0;
+  std::vector<ColPass> fwd_passes, inv_passes;
+  // spectra
+  DevBuf<cplx> Ahat, Chat, T1, T2, Bhat;
+  int bhat_cap_days = 0;
+  int chunk_days = 1;
+  // kernels (device COO + dense staging)
+  DevBuf<int> krow, kcol;
+  DevBuf<double> kval;
+  std::vector<int64_t> koff;
+  std::vector<int> kshape;
+  int nk = 0, Kmax = 0;
+  bool kernels_on_device = false;
+  DevBuf<double> kdense;
+  int bhat_first = -1, bhat_count = 0;  // which days' transforms Bhat currently holds
+  // records
+  std::vector<double*> recs[4];
+  // stats
+  DevBuf<double> rowsum;       // [nstat][N]
+  DevBuf<long long> rowcnt;    // [nstat][N]
+  DevBuf<long long> rowoff;    // [N]
+  DevBuf<unsigned long long> padmax;
+  DevBuf<DayStats> dstats;
+  DevBuf<int> flags;
+  int nstat = 0;
+  // staging for fetch / uploads
+  DevBuf<int> orow, ocol;
+  DevBuf<double> oval;
+  DevBuf<const double*> wptr;
+  DevBuf<double> wval;
+  bool have_state = false;
+};
+
+// ------------------------------------------------------------------ helpers
+static int row_threads(int L) { return L <= 1024 ? 256 : (L <= 2560 ? 512 : 1024); }
+static int row_pairs(const FftProg& P) {
+  int rp = 2048 / std::max(1, P.L);
+  rp = std::max(1, std::min(8, rp));
+  return rp;
+}
+static int col_wsh(int L) {
+  int w = 4096 / std::max(1, L);
+  int sh = 2;
+  while ((1 << (sh + 1)) <= w && sh < 5) ++sh;
+  return sh;
+}
+
+static int set_lds_attr() {
+  static bool done = false;
+  if (done) return PS_OK;
+  const void* ks[] = {(const void*)k_row_fwd<false>, (const void*)k_row_fwd<true>,
+                      (const void*)k_row_inv<false>, (const void*)k_row_inv<true>,
+                      (const void*)k_col<PS_FWD, false>, (const void*)k_col<PS_FWD, true>,
+                      (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>};
+  for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  done = true;
+  return PS_OK;
+}
+
+static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
+                          SrcMap rmap, SrcMap cmap, cplx* dst, int batch, const int* pred) {
+  RowFwdArgs a;
+  a.src = src; a.src_bstride = src_bstride; a.src_ld = src_ld;
+  a.rmap = rmap; a.cmap = cmap;
+  a.dst = dst; a.dst_bstride = (int64_t)s->Pf * s->ld;
+  a.H = s->H; a.ld = s->ld; a.P = s->Pf;
+  a.prog = s->row_plan.prog;
+  a.rp = row_pairs(a.prog);
+  a.pred = pred;
+  const int npairs = (s->Pf + 1) / 2;
+  dim3 grid((npairs + a.rp - 1) / a.rp, batch);
+  const int thr = row_threads(a.prog.L);
+  const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
+  if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
+  if (s->row_plan.generic)
+    hipLaunchKernelGGL(k_row_fwd<true>, grid, dim3(thr), lds, s->stream, a);
+  else
+    hipLaunchKernelGGL(k_row_fwd<false>, grid, dim3(thr), lds, s->stream, a);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+template <int DIR>
+static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cplx* src2,
+                      cplx* prod, cplx* dst, int batch, int64_t src2_bstride, const int* pred) {
+  ColArgs a;
+  a.src = src; a.src2 = src2; a.prod_dst = prod; a.dst = dst;
+  const int64_t bs = (int64_t)s->Pf * s->ld;
+  a.src_bstride = bs; a.src2_bstride = src2_bstride; a.prod_bstride = bs; a.dst_bstride = bs;
+  a.ld = s->ld; a.ncols = s->H;
+  a.prog = cp.plan->prog;
+  a.wsh = col_wsh(a.prog.L);
+  a.n_outer = cp.n_outer;
+  a.in_base_mul = cp.in_base_mul; a.in_stride = cp.in_stride;
+  a.out_base_mul = cp.out_base_mul; a.out_stride = cp.out_stride;
+  a.tw_mode = cp.tw_mode;
+  a.tp_lo = s->tp_lo.p; a.tp_hi = s->tp_hi.p; a.tp_shift = s->tp_shift;
+  a.pred = pred;
+  const int W = 1 << a.wsh;
+  const int ntiles = (s->H + W - 1) / W;
+  dim3 grid((unsigned)(ntiles * cp.n_outer), batch);
+  size_t lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
+  while (lds > (size_t)kMaxLds && a.wsh > 0) {
+    --a.wsh;
+    lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
+  }
+  if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", lds);
+  {
+    const int W2 = 1 << a.wsh;
+    grid.x = (unsigned)(((s->H + W2 - 1) / W2) * cp.n_outer);
+  }
+  if (cp.plan->generic)
+    hipLaunchKernelGGL((k_col<DIR, true>), grid, dim3(256), lds, s->stream, a);
+  else
+    hipLaunchKernelGGL((k_col<DIR, false>), grid, dim3(256), lds, s->stream, a);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_slot, int batch,
+                          double negval, double stat_scale) {
+  RowInvArgs a;
+  a.src = src; a.src_bstride = (int64_t)s->Pf * s->ld;
+  a.H = s->H; a.ld = s->ld; a.P = s->Pf; a.N = s->N;
+  a.prog = s->row_plan.prog;
+  a.rp = row_pairs(a.prog);
+  a.scale = 1.0 / ((double)s->Pf * (double)s->Pf);
+  a.rec = rec; a.rec_bstride = (int64_t)s->N * s->N;
+  a.negval = negval; a.stat_scale = stat_scale;
+  a.rowsum = s->rowsum.p + (int64_t)stat_slot * s->N;
+  a.rowcnt = s->rowcnt.p + (int64_t)stat_slot * s->N;
+  a.padmax = s->padmax.p + stat_slot;
+  a.stat_bstride = s->N;
+  const int npairs = (s->Pf + 1) / 2;
+  dim3 grid((npairs + a.rp - 1) / a.rp, batch);
+  const int thr = row_threads(a.prog.L);
+  const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx) +
+                     4 * (thr / 64) * sizeof(double);
+  if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
+  if (s->row_plan.generic)
+    hipLaunchKernelGGL(k_row_inv<true>, grid, dim3(thr), lds, s->stream, a);
+  else
+    hipLaunchKernelGGL(k_row_inv<false>, grid, dim3(thr), lds, s->stream, a);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+// forward 2-D transform of `batch` real sources into `out`
+static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_ld, SrcMap rmap,
+                 SrcMap cmap, cplx* out, int batch, const int* pred) {
+  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred));
+  if (s->fwd_passes.size() == 1) {
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred));
+  } else {
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[1], s->T2.p, nullptr, nullptr, out, batch, 0, pred));
+  }
+  return PS_OK;
+}
+
+// inverse 2-D transform of (A [* B]) into record `rec`; optionally stores the product
+static int inv2d(ps_solver* s, const cplx* A, const cplx* B, cplx* prod, double* rec,
+                 int stat_slot, double negval, double stat_scale) {
+  if (s->inv_passes.size() == 1) {
+    PS_TRY(launch_col<PS_INV>(s, s->inv_passes[0], A, B, prod, s->T1.p, 1, 0, nullptr));
+    PS_TRY(launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale));
+  } else {
+    PS_TRY(launch_col<PS_INV>(s, s->inv_passes[0], A, B, prod, s->T1.p, 1, 0, nullptr));
+    PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
+    PS_TRY(launch_row_inv(s, s->T2.p, rec, stat_slot, 1, negval, stat_scale));
+  }
+  return PS_OK;
+}
+
+static SrcMap map_plain(int n, int P) { return SrcMap{n, 0, P, 0}; }
+// odd kernel of half width m centred at the torus origin (CalcSol.py:61-64)
+static SrcMap map_wrap(int m, int P) { return SrcMap{m + 1, m, P - m, 0}; }
+
+static int ensure_record(ps_solver* s, int kind, int idx) {
+  auto& v = s->recs[kind];
+  if ((int)v.size() <= idx) v.resize(idx + 1, nullptr);
+  if (!v[idx]) {
+    hipError_t e = hipMalloc((void**)&v[idx], (size_t)s->N * s->N * sizeof(double));
+    if (e != hipSuccess) return ps_fail(PS_ERR_OOM, "record allocation failed: %s", hipGetErrorString(e));
+  }
+  return PS_OK;
+}
+
+// n day slots plus one scratch slot (index nstat) for on-demand record statistics.
+// Growing discards earlier statistics; they are rewritten by every run.
+static int ensure_stats(ps_solver* s, int n) {
+  if (n <= s->nstat) return PS_OK;
+  PS_TRY(s->rowsum.ensure((size_t)(n + 1) * s->N));
+  PS_TRY(s->rowcnt.ensure((size_t)(n + 1) * s->N));
+  PS_TRY(s->padmax.ensure(n + 1));
+  PS_TRY(s->dstats.ensure(n + 1));
+  PS_TRY(s->flags.ensure(n + 1));
+  s->nstat = n;
+  return PS_OK;
+}
+
+static int finalize_day(ps_solver* s, int slot, int renorm) {
+  hipLaunchKernelGGL(k_day_finalize, dim3(1), dim3(256), 0, s->stream,
+                     s->rowsum.p + (int64_t)slot * s->N, s->rowcnt.p + (int64_t)slot * s->N,
+                     s->padmax.p + slot, s->N, renorm, s->dstats.p + slot, s->flags.p + slot);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+// truncate to the domain and re-transform when the day's flag is set (CalcSol.py:200-201)
+static int refft_if_flag(ps_solver* s, const double* rec, cplx* hat, int slot) {
+  return fwd2d(s, rec, 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), hat, 1,
+               s->flags.p + slot);
+}
+
+// ------------------------------------------------------------------- create
+extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode) {
+  if (!out) return ps_fail(PS_ERR_BAD_ARG, "null output handle");
+  *out = nullptr;
+  if (dom_len < 1 || max_shape < 1) return ps_fail(PS_ERR_BAD_SHAPE, "dom_len=%d max_shape=%d", dom_len, max_shape);
+  if (mode != PS_MODE_EXACT && mode != PS_MODE_FAST) return ps_fail(PS_ERR_BAD_ARG, "mode %d", mode);
+  PS_TRY(ps_use_device(device));
+  PS_TRY(set_lds_attr());
+  ps_solver* s = new ps_solver();
+  s->device = device;
+  s->N = dom_len;
+  s->M = max_shape / 2;
+  s->Pref = dom_len + s->M;  // CalcSol.py:20-21, cuda_lib.py:26-28
+  s->mode = mode;
+  s->Pf = mode == PS_MODE_FAST ? ps_next_fast_len(s->Pref) : s->Pref;
+  s->H = s->Pf / 2 + 1;
+  s->ld = (s->H + 7) & ~7;
+  auto fail = [&](int rc) {
+    ps_solver_destroy(s);
+    return rc;
+  };
+  if (!ps_build_plan(s->Pf, true, &s->row_plan.host))
+    return fail(ps_fail(PS_ERR_UNSUPPORTED, "cannot plan a length-%d FFT (prime factor > %d); use PS_MODE_FAST",
+                        s->Pf, PS_MAX_GENERIC_RADIX));
+  if ((size_t)(row_pitch(s->row_plan.host.prog) + 512) * sizeof(cplx) > (size_t)kMaxLds)
+    return fail(ps_fail(PS_ERR_UNSUPPORTED, "pad size %d exceeds the LDS-resident row limit", s->Pf));
+  int rc = s->row_plan.upload();
+  if (rc) return fail(rc);
+  s->L1 = ps_choose_col_split(s->Pf, 1200);
+  s->split = s->L1 != s->Pf;
+  if (s->split) {
+    s->L2 = s->Pf / s->L1;
+    if (!ps_build_plan(s->L1, false, &s->col_plan1.host) || !ps_build_plan(s->L2, false, &s->col_plan2.host))
+      return fail(ps_fail(PS_ERR_UNSUPPORTED, "cannot plan column FFT %d = %d x %d", s->Pf, s->L1, s->L2));
+    if ((rc = s->col_plan1.upload())) return fail(rc);
+    if ((rc = s->col_plan2.upload())) return fail(rc);
+    s->fwd_passes = {ColPass{&s->col_plan1, s->L2, 1, s->L2, 1, s->L2, 1},
+                     ColPass{&s->col_plan2, s->L1, s->L2, 1, 1, s->L1, 0}};
+    s->inv_passes = {ColPass{&s->col_plan2, s->L1, 1, s->L1, s->L2, 1, 0},
+                     ColPass{&s->col_plan1, s->L2, 1, s->L2, 1, s->L2, 2}};
+  } else {
+    s->L2 = 1;
+    if (!ps_build_plan(s->Pf, false, &s->col_plan1.host))
+      return fail(ps_fail(PS_ERR_UNSUPPORTED, "cannot plan column FFT %d", s->Pf));
+    if ((rc = s->col_plan1.upload())) return fail(rc);
+    s->fwd_passes = {ColPass{&s->col_plan1, 1, 0, 1, 0, 1, 0}};
+    s->inv_passes = {ColPass{&s->col_plan1, 1, 0, 1, 0, 1, 0}};
+  }
+  {
+    HostTwiddle tw;
+    ps_build_twiddle(s->Pf, &tw);
+    s->tp_shift = tw.shift;
+    if ((rc = s->tp_lo.ensure(tw.lo.size()))) return fail(rc);
+    if ((rc = s->tp_hi.ensure(tw.hi.size()))) return fail(rc);
+    hipError_t e1 = hipMemcpy(s->tp_lo.p, tw.lo.data(), tw.lo.size() * sizeof(cplx), hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(s->tp_hi.p, tw.hi.data(), tw.hi.size() * sizeof(cplx), hipMemcpyHostToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(ps_fail(PS_ERR_HIP, "twiddle upload failed"));
+  }
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return fail(ps_fail(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+  const size_t spec = (size_t)s->Pf * s->ld;
+  const size_t budget = (size_t)3 << 30;  // bytes of batched kernel spectra per chunk
+  s->chunk_days = (int)std::max<size_t>(1, std::min<size_t>(64, budget / (spec * sizeof(cplx))));
+  if ((rc = s->Ahat.ensure(spec))) return fail(rc);
+  if ((rc = s->rowoff.ensure(s->N))) return fail(rc);
+  if ((rc = ensure_stats(s, 4))) return fail(rc);
+  *out = s;
+  return PS_OK;
+}
+
+extern "C" int ps_solver_destroy(ps_solver* s) {
+  if (!s) return PS_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) {
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamDestroy(s->stream);
+  }
+  s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
+  s->tp_lo.release(); s->tp_hi.release();
+  s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release();
+  s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release();
+  for (auto& v : s->recs)
+    for (double* p : v)
+      if (p) (void)hipFree(p);
+  s->rowsum.release(); s->rowcnt.release(); s->rowoff.release(); s->padmax.release();
+  s->dstats.release(); s->flags.release();
+  s->orow.release(); s->ocol.release(); s->oval.release(); s->wptr.release(); s->wval.release();
+  delete s;
+  return PS_OK;
+}
+
+extern "C" int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  if (dom_len) *dom_len = s->N;
+  if (P) *P = s->Pref;
+  if (Pfft) *Pfft = s->Pf;
+  if (H) *H = s->H;
+  return PS_OK;
+}
+
+extern "C" int ps_solver_sync(ps_solver* s) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  PS_HIP(hipSetDevice(s->device));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  return PS_OK;
+}
+
+static int ensure_temps(ps_solver* s, int batch) {
+  const size_t spec = (size_t)s->Pf * s->ld;
+  PS_TRY(s->T1.ensure(spec * batch));
+  if (s->split) PS_TRY(s->T2.ensure(spec * batch));
+  return PS_OK;
+}
+
+static int check_coo(const int32_t* row, const int32_t* col, int64_t nnz, int lim, const char* what) {
+  for (int64_t i = 0; i < nnz; ++i)
+    if (row[i] < 0 || row[i] >= lim || col[i] < 0 || col[i] >= lim)
+      return ps_fail(PS_ERR_BAD_SHAPE, "%s: entry %lld (%d,%d) outside %d x %d", what, (long long)i, row[i],
+                     col[i], lim, lim);
+  return PS_OK;
+}
+
+static int scatter_from_device(ps_solver* s, const int* row, const int* col, const double* val,
+                               int64_t nnz, double* dst, int ld, int off) {
+  if (nnz <= 0) return PS_OK;
+  const int thr = 256;
+  const int blocks = (int)std::min<int64_t>((nnz + thr - 1) / thr, 4096);
+  hipLaunchKernelGGL(k_scatter_coo, dim3(blocks), dim3(thr), 0, s->stream, row, col, val, nnz, dst, ld, off, off);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+static int upload_coo(ps_solver* s, const int32_t* row, const int32_t* col, const double* val, int64_t nnz) {
+  PS_TRY(s->orow.ensure(std::max<int64_t>(nnz, 1)));
+  PS_TRY(s->ocol.ensure(std::max<int64_t>(nnz, 1)));
+  PS_TRY(s->oval.ensure(std::max<int64_t>(nnz, 1)));
+  if (nnz > 0) {
+    PS_HIP(hipMemcpyAsync(s->orow.p, row, nnz * 4, hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->ocol.p, col, nnz * 4, hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->oval.p, val, nnz * 8, hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipStreamSynchronize(s->stream));  // host buffers are caller-owned: copy completes before return
+  }
+  return PS_OK;
+}
+
+int ps_solver_set_state_device_coo(ps_solver* s, const int* row, const int* col, const double* val,
+                                   int64_t nnz, int off) {
+  PS_TRY(ensure_record(s, PS_REC_STATE, 0));
+  PS_TRY(ensure_temps(s, 1));
+  double* rec = s->recs[PS_REC_STATE][0];
+  PS_HIP(hipMemsetAsync(rec, 0, (size_t)s->N * s->N * sizeof(double), s->stream));
+  PS_TRY(scatter_from_device(s, row, col, val, nnz, rec, s->N, off));
+  PS_TRY(fwd2d(s, rec, 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), s->Ahat.p, 1, nullptr));
+  s->have_state = true;
+  return PS_OK;
+}
+
+extern "C" int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const int32_t* col,
+                                       const double* val, int64_t nnz) {
+  if (!s || nnz < 0 || (nnz > 0 && (!row || !col || !val))) return ps_fail(PS_ERR_BAD_ARG, "set_state_coo: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(check_coo(row, col, nnz, s->N, "state"));
+  PS_TRY(upload_coo(s, row, col, val, nnz));
+  return ps_solver_set_state_device_coo(s, s->orow.p, s->ocol.p, s->oval.p, nnz, 0);
+}
+
+// transform `count` kernels starting at day `first` into Bhat[0..count)
+static int transform_kernels(ps_solver* s, int first, int count) {
+  const int K = s->Kmax, M = K / 2;
+  const size_t spec = (size_t)s->Pf * s->ld;
+  PS_TRY(s->kdense.ensure((size_t)count * K * K));
+  PS_TRY(s->Bhat.ensure(spec * count));
+  PS_TRY(ensure_temps(s, count));
+  PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)count * K * K * sizeof(double), s->stream));
+  for (int d = 0; d < count; ++d) {
+    const int64_t o = s->koff[first + d], n = s->koff[first + d + 1] - o;
+    const int off = M - s->kshape[first + d] / 2;
+    PS_TRY(scatter_from_device(s, s->krow.p + o, s->kcol.p + o, s->kval.p + o, n,
+                               s->kdense.p + (size_t)d * K * K, K, off));
+  }
+  PS_TRY(fwd2d(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count, nullptr));
+  s->bhat_first = first;
+  s->bhat_count = count;
+  return PS_OK;
+}
+
+static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape) {
+  s->koff.assign(off, off + nk + 1);
+  s->kshape.assign(kshape, kshape + nk);
+  s->nk = nk;
+  s->Kmax = 1;
+  for (int d = 0; d < nk; ++d) {
+    if (kshape[d] < 1 || kshape[d] % 2 == 0)
+      return ps_fail(PS_ERR_BAD_SHAPE, "kernel %d has even/invalid shape %d (CalcSol.py:58)", d, kshape[d]);
+    if (kshape[d] / 2 > s->M)
+      return ps_fail(PS_ERR_BAD_SHAPE, "kernel %d shape %d exceeds max_shape %d", d, kshape[d], 2 * s->M + 1);
+    s->Kmax = std::max(s->Kmax, kshape[d]);
+  }
+  if (2 * (s->Kmax / 2) + 1 > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "kernel larger than the pad");
+  s->bhat_first = -1;
+  s->bhat_count = 0;
+  s->kernels_on_device = true;
+  return PS_OK;
+}
+
+extern "C" int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                                    const int32_t* row, const int32_t* col, const double* val) {
+  if (!s || nk < 0 || !off || (nk > 0 && !kshape)) return ps_fail(PS_ERR_BAD_ARG, "set_kernels: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  const int64_t tot = off[nk];
+  for (int d = 0; d < nk; ++d) {
+    if (off[d + 1] < off[d]) return ps_fail(PS_ERR_BAD_ARG, "offsets not monotone");
+    PS_TRY(check_coo(row + off[d], col + off[d], off[d + 1] - off[d], kshape[d], "kernel"));
+  }
+  PS_TRY(s->krow.ensure(std::max<int64_t>(tot, 1)));
+  PS_TRY(s->kcol.ensure(std::max<int64_t>(tot, 1)));
+  PS_TRY(s->kval.ensure(std::max<int64_t>(tot, 1)));
+  if (tot > 0) {
+    PS_HIP(hipMemcpyAsync(s->krow.p, row, tot * 4, hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->kcol.p, col, tot * 4, hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->kval.p, val, tot * 8, hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipStreamSynchronize(s->stream));
+  }
+  return set_kernels_common(s, nk, off, kshape);
+}
+
+// used by the model module (kernels already on the device)
+int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                                  const int* row, const int* col, const double* val) {
+  const int64_t tot = off[nk];
+  PS_TRY(s->krow.ensure(std::max<int64_t>(tot, 1)));
+  PS_TRY(s->kcol.ensure(std::max<int64_t>(tot, 1)));
+  PS_TRY(s->kval.ensure(std::max<int64_t>(tot, 1)));
+  if (tot > 0) {
+    PS_HIP(hipMemcpyAsync(s->krow.p, row, tot * 4, hipMemcpyDeviceToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->kcol.p, col, tot * 4, hipMemcpyDeviceToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->kval.p, val, tot * 8, hipMemcpyDeviceToDevice, s->stream));
+  }
+  return set_kernels_common(s, nk, off, kshape);
+}
+
+extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_scale,
+                            int renorm) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "chain_run before set_state");
+  if (!s->kernels_on_device || first < 0 || count < 0 || first + count > s->nk)
+    return ps_fail(PS_ERR_STATE, "chain_run: days [%d,%d) not uploaded (nk=%d)", first, first + count, s->nk);
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(ensure_stats(s, std::max(4, first + count)));
+  for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
+  PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
+  for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
+    const int cn = std::min(s->chunk_days, first + count - c0);
+    PS_TRY(transform_kernels(s, c0, cn));
+    for (int d = c0; d < c0 + cn; ++d) {
+      const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
+      double* rec = s->recs[PS_REC_CHAIN][d];
+      PS_TRY(inv2d(s, s->Ahat.p, B, s->Ahat.p, rec, d, negval, stat_scale));
+      PS_TRY(finalize_day(s, d, renorm));
+      PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
+    }
+  }
+  return PS_OK;
+}
+
+extern "C" int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out) {
+  if (!s || !out || first < 0 || count < 0 || first + count > s->nstat) return ps_fail(PS_ERR_BAD_ARG, "chain_stats: bad range");
+  PS_HIP(hipSetDevice(s->device));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  static_assert(sizeof(ps_day_stats) == sizeof(DayStats), "stats layout");
+  PS_HIP(hipMemcpy(out, s->dstats.p + first, (size_t)count * sizeof(DayStats), hipMemcpyDeviceToHost));
+  return PS_OK;
+}
+
+__global__ void k_cmul_inplace(cplx* a, const cplx* b, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    a[i] = cmul(a[i], b[i]);
+}
+
+extern "C" int ps_solver_fftconv2_coo(ps_solver* s, const int32_t* row, const int32_t* col,
+                                      const double* val, int64_t nnz, int kshape) {
+  if (!s || nnz < 0) return ps_fail(PS_ERR_BAD_ARG, "fftconv2: bad arguments");
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "fftconv2 before set_state");
+  if (kshape < 1 || kshape % 2 == 0) return ps_fail(PS_ERR_BAD_SHAPE, "kernel shape %d must be odd (CalcSol.py:58)", kshape);
+  if (kshape > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "kernel shape %d larger than the pad %d", kshape, s->Pf);
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(check_coo(row, col, nnz, kshape, "kernel"));
+  PS_TRY(upload_coo(s, row, col, val, nnz));
+  const int K = kshape, M = K / 2;
+  const size_t spec = (size_t)s->Pf * s->ld;
+  PS_TRY(s->kdense.ensure((size_t)K * K));
+  PS_TRY(s->Bhat.ensure(spec));
+  PS_TRY(ensure_temps(s, 1));
+  s->bhat_first = -1;
+  PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)K * K * sizeof(double), s->stream));
+  PS_TRY(scatter_from_device(s, s->orow.p, s->ocol.p, s->oval.p, nnz, s->kdense.p, K, 0));
+  PS_TRY(fwd2d(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, 1, nullptr));
+  hipLaunchKernelGGL(k_cmul_inplace, dim3(2048), dim3(256), 0, s->stream, s->Ahat.p, s->Bhat.p, (int64_t)spec);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+extern "C" int ps_solver_get_cursol(ps_solver* s, double negval, double stat_scale, int renorm,
+                                    ps_day_stats* stats) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "get_cursol before set_state");
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(ensure_record(s, PS_REC_CHAIN, 0));
+  PS_TRY(ensure_temps(s, 1));
+  PS_HIP(hipMemsetAsync(s->padmax.p, 0, sizeof(unsigned long long), s->stream));
+  double* rec = s->recs[PS_REC_CHAIN][0];
+  PS_TRY(inv2d(s, s->Ahat.p, nullptr, nullptr, rec, 0, negval, stat_scale));
+  PS_TRY(finalize_day(s, 0, renorm));
+  PS_TRY(refft_if_flag(s, rec, s->Ahat.p, 0));
+  if (stats) PS_TRY(ps_chain_stats(s, 0, 1, stats));
+  return PS_OK;
+}
+
+extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off, const int32_t* row,
+                                    const int32_t* col, const double* val, double negval,
+                                    double stat_scale, ps_day_stats* stats) {
+  if (!s || nfilt < 0 || !off) return ps_fail(PS_ERR_BAD_ARG, "back_solve: bad arguments");
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "back_solve before set_state");
+  if (s->N % 2 == 0) return ps_fail(PS_ERR_BAD_SHAPE, "back_solve needs an odd domain (filters are N x N)");
+  if (2 * (s->N / 2) + 1 > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "filter larger than the pad");
+  PS_HIP(hipSetDevice(s->device));
+  const size_t spec = (size_t)s->Pf * s->ld;
+  const int K = s->N, M = K / 2;
+  PS_TRY(s->Chat.ensure(spec));
+  PS_TRY(s->Bhat.ensure(spec));
+  PS_TRY(s->kdense.ensure((size_t)K * K));
+  PS_TRY(ensure_temps(s, 1));
+  PS_TRY(ensure_stats(s, std::max(4, nfilt)));
+  s->bhat_first = -1;
+  // the back-solve statistics live in their own slots after the call; reuse slots [0,nfilt)
+  PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
+  PS_HIP(hipMemsetAsync(s->padmax.p, 0, (size_t)std::max(1, nfilt) * sizeof(unsigned long long), s->stream));
+  for (int i = nfilt - 1; i >= 0; --i) {
+    const int64_t o = off[i], n = off[i + 1] - o;
+    PS_TRY(check_coo(row + o, col + o, n, K, "filter"));
+    PS_TRY(upload_coo(s, row + o, col + o, val + o, n));
+    PS_TRY(ensure_record(s, PS_REC_BACK, i));
+    PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)K * K * sizeof(double), s->stream));
+    PS_TRY(scatter_from_device(s, s->orow.p, s->ocol.p, s->oval.p, n, s->kdense.p, K, 0));
+    PS_TRY(fwd2d(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, 1, nullptr));
+    double* rec = s->recs[PS_REC_BACK][i];
+    PS_TRY(inv2d(s, s->Chat.p, s->Bhat.p, s->Chat.p, rec, i, negval, stat_scale));
+    PS_TRY(finalize_day(s, i, 0));
+    PS_TRY(refft_if_flag(s, rec, s->Chat.p, i));  // cuda_lib.py:208-214 semantics
+  }
+  if (stats && nfilt > 0) PS_TRY(ps_chain_stats(s, 0, nfilt, stats));
+  return PS_OK;
+}
+
+// ------------------------------------------------------------------ records
+static int get_record(ps_solver* s, int kind, int idx, double** out) {
+  if (kind < 0 || kind > 3 || idx < 0 || idx >= (int)s->recs[kind].size() || !s->recs[kind][idx])
+    return ps_fail(PS_ERR_STATE, "record (%d,%d) does not exist", kind, idx);
+  *out = s->recs[kind][idx];
+  return PS_OK;
+}
+
+extern "C" int ps_record_stats(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                               int renorm, ps_day_stats* out) {
+  if (!s || !out) return ps_fail(PS_ERR_BAD_ARG, "record_stats: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  double* rec;
+  PS_TRY(get_record(s, kind, idx, &rec));
+  PS_TRY(ensure_stats(s, 4));
+  const int slot = s->nstat;  // scratch slot
+  PS_HIP(hipMemsetAsync(s->padmax.p + slot, 0, sizeof(unsigned long long), s->stream));
+  hipLaunchKernelGGL(k_row_stats, dim3(s->N), dim3(256), 0, s->stream, rec, s->N, stat_scale, negval,
+                     s->rowsum.p + (int64_t)slot * s->N, s->rowcnt.p + (int64_t)slot * s->N);
+  PS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_day_finalize, dim3(1), dim3(256), 0, s->stream, s->rowsum.p + (int64_t)slot * s->N,
+                     s->rowcnt.p + (int64_t)slot * s->N, s->padmax.p + slot, s->N, renorm,
+                     s->dstats.p + slot, (int*)nullptr);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipStreamSynchronize(s->stream));
+  PS_HIP(hipMemcpy(out, s->dstats.p + slot, sizeof(DayStats), hipMemcpyDeviceToHost));
+  return PS_OK;
+}
+
+extern "C" int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                                   double delta, double post_scale, int32_t* row, int32_t* col,
+                                   double* val, int64_t cap, int64_t* nnz_out) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  PS_HIP(hipSetDevice(s->device));
+  double* rec;
+  PS_TRY(get_record(s, kind, idx, &rec));
+  PS_TRY(ensure_stats(s, 4));
+  const int slot = s->nstat;  // scratch slot
+  double* rs = s->rowsum.p + (int64_t)slot * s->N;
+  long long* rc = s->rowcnt.p + (int64_t)slot * s->N;
+  hipLaunchKernelGGL(k_row_stats, dim3(s->N), dim3(256), 0, s->stream, rec, s->N, stat_scale, negval, rs, rc);
+  PS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, s->stream, rc, s->N, s->rowoff.p);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipStreamSynchronize(s->stream));
+  long long last_off = 0, last_cnt = 0;
+  PS_HIP(hipMemcpy(&last_off, s->rowoff.p + (s->N - 1), sizeof(long long), hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(&last_cnt, rc + (s->N - 1), sizeof(long long), hipMemcpyDeviceToHost));
+  const int64_t nnz = last_off + last_cnt;
+  if (nnz_out) *nnz_out = nnz;
+  if (!row || !col || !val) return PS_OK;  // count only
+  if (cap < nnz) return ps_fail(PS_ERR_BAD_ARG, "fetch_coo: capacity %lld < nnz %lld", (long long)cap, (long long)nnz);
+  if (nnz == 0) return PS_OK;
+  PS_TRY(s->orow.ensure(nnz));
+  PS_TRY(s->ocol.ensure(nnz));
+  PS_TRY(s->oval.ensure(nnz));
+  const int thr = 256;
+  const int blocks = (s->N * 64 + thr - 1) / thr;
+  hipLaunchKernelGGL(k_compact_rows, dim3(blocks), dim3(thr), 0, s->stream, rec, s->N, stat_scale, negval,
+                     delta, post_scale, s->rowoff.p, s->orow.p, s->ocol.p, s->oval.p);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(row, s->orow.p, nnz * 4, hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipMemcpyAsync(col, s->ocol.p, nnz * 4, hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipMemcpyAsync(val, s->oval.p, nnz * 8, hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  return PS_OK;
+}
+
+extern "C" int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out) {
+  if (!s || !out) return ps_fail(PS_ERR_BAD_ARG, "fetch_dense: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  double* rec;
+  PS_TRY(get_record(s, kind, idx, &rec));
+  PS_HIP(hipMemcpyAsync(out, rec, (size_t)s->N * s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  return PS_OK;
+}
+
+extern "C" int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx, const double* w) {
+  if (!s || n < 1 || !kind || !idx || !w) return ps_fail(PS_ERR_BAD_ARG, "weighted_sum: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  std::vector<const double*> ptrs(n);
+  for (int d = 0; d < n; ++d) {
+    double* r;
+    PS_TRY(get_record(s, kind[d], idx[d], &r));
+    ptrs[d] = r;
+  }
+  PS_TRY(ensure_record(s, PS_REC_WSUM, 0));
+  PS_TRY(s->wptr.ensure(n));
+  PS_TRY(s->wval.ensure(n));
+  PS_HIP(hipMemcpyAsync(s->wptr.p, ptrs.data(), n * sizeof(double*), hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipMemcpyAsync(s->wval.p, w, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  const int64_t tot = (int64_t)s->N * s->N;
+  hipLaunchKernelGGL(k_weighted_sum, dim3(2048), dim3(256), 0, s->stream, (const double* const*)s->wptr.p,
+                     s->wval.p, n, tot, s->recs[PS_REC_WSUM][0]);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+// ----------------------------------------------------------------- spectrum
+extern "C" int ps_solver_get_spectrum(ps_solver* s, double* out) {
+  if (!s || !out) return ps_fail(PS_ERR_BAD_ARG, "get_spectrum: bad arguments");
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "get_spectrum before set_state");
+  PS_HIP(hipSetDevice(s->device));
+  const size_t full = (size_t)s->Pf * s->Pf;
+  DevBuf<cplx> tmp;
+  PS_TRY(tmp.ensure(full));
+  hipLaunchKernelGGL(k_expand_spectrum, dim3(2048), dim3(256), 0, s->stream, s->Ahat.p, s->Pf, s->H, s->ld, tmp.p);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, tmp.p, full * sizeof(cplx), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  tmp.release();
+  if (e != hipSuccess) return ps_fail(PS_ERR_HIP, "get_spectrum: %s", hipGetErrorString(e));
+  return PS_OK;
+}
+
+extern "C" int ps_solver_set_spectrum(ps_solver* s, const double* in) {
+  if (!s || !in) return ps_fail(PS_ERR_BAD_ARG, "set_spectrum: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  const size_t full = (size_t)s->Pf * s->Pf;
+  DevBuf<cplx> tmp;
+  PS_TRY(tmp.ensure(full));
+  hipError_t e = hipMemcpyAsync(tmp.p, in, full * sizeof(cplx), hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_take_half_spectrum, dim3(2048), dim3(256), 0, s->stream, tmp.p, s->Pf, s->H, s->ld, s->Ahat.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  tmp.release();
+  if (e != hipSuccess) return ps_fail(PS_ERR_HIP, "set_spectrum: %s", hipGetErrorString(e));
+  s->have_state = true;
+  return PS_OK;
+}

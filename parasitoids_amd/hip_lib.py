@@ -1,0 +1,205 @@
+"""HIP methods for convolutions -- the MI355X counterpart of the reference's
+`cuda_lib.py`: class `HipSolve` keeps `cuda_lib.CudaSolve`'s constructor and
+its three methods (cuda_lib.py:18, :58, :98, :145), computing in fp64 on the
+device through libparasitoid_hip.so.
+
+Importing this module raises ImportError when the shared library or a GPU is
+missing, exactly the condition under which the reference's
+`CalcSol.get_solutions` falls back (CalcSol.py:161-172).
+"""
+import ctypes as C
+
+import numpy as np
+from scipy import sparse
+
+from . import _lib as L
+
+L.load()
+L.require_device()
+
+
+def _coo_arrays(A):
+    A = sparse.coo_matrix(A)
+    return L.i32(A.row), L.i32(A.col), L.f64(A.data), A.shape
+
+
+class HipSolve():
+    """Device-resident Fourier-space solution, cf. `cuda_lib.CudaSolve`."""
+
+    def __init__(self, A, max_shape, mode='exact', device=None):
+        '''Initialize the solver with the fft of the solution after the first day.
+
+        Args:
+            A: First day's spread, sparse matrix (square, N x N)
+            max_shape: Shape of the largest filter (cuda_lib.py:18-28)
+            mode: 'exact' transforms on the reference's pad P = N + max_shape//2;
+                  'fast' on the next even 7-smooth size >= P'''
+        self._h = L._VP()
+        self._lib = L.load()
+        row, col, val, shape = _coo_arrays(A)
+        if shape[0] != shape[1]:
+            raise ValueError('domain must be square, got {}'.format(shape))
+        ms = np.array(max_shape).astype(int).ravel()
+        if ms.size == 1:
+            ms = np.array([ms[0], ms[0]])
+        if ms[0] != ms[1]:
+            raise ValueError('max_shape must be square, got {}'.format(tuple(ms)))
+        self.dom_len = int(shape[0])
+        mmid = ms // 2
+        self.pad_shape = (int(shape[0] + mmid[0]), int(shape[1] + mmid[1]))
+        dev = L.default_device() if device is None else device
+        L.check(self._lib.ps_solver_create(C.byref(self._h), dev, self.dom_len, int(ms[0]),
+                                           L.MODE_FAST if mode == 'fast' else L.MODE_EXACT))
+        info = [C.c_int32() for _ in range(4)]
+        L.check(self._lib.ps_solver_info(self._h, *[C.byref(v) for v in info]))
+        self.fft_len = info[2].value
+        L.check(self._lib.ps_solver_set_state_coo(self._h, L.p_i32(row), L.p_i32(col),
+                                                  L.p_f64(val), len(val)))
+        self._nk = 0
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.ps_solver_destroy(self._h)
+            self._h = L._VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -------------------------------------------------------- CudaSolve API
+    def fftconv2(self, B, mem_print=False):
+        '''Update current fourier solution with filter B (cuda_lib.py:58-94).
+
+        Args:
+            B: 2D sparse matrix with odd, square shape'''
+        row, col, val, shape = _coo_arrays(B)
+        if shape[0] != shape[1]:
+            raise ValueError('filter must be square, got {}'.format(shape))
+        L.check(self._lib.ps_solver_fftconv2_coo(self._h, L.p_i32(row), L.p_i32(col),
+                                                 L.p_f64(val), len(val), int(shape[0])))
+
+    def get_cursol(self, dom_shape, negval=1e-8):
+        '''Return the current solution (requires ifft) with small values removed
+        (cuda_lib.py:98-140); re-transforms the truncated solution when mass has
+        reached the pad region.
+
+        Returns:
+            coo matrix, current solution with shape (dom_len,dom_len)'''
+        self._check_dom(dom_shape)
+        st = L.DayStats()
+        L.check(self._lib.ps_solver_get_cursol(self._h, negval, 1.0, 0, C.byref(st)))
+        self.last_flag = bool(st.flag)
+        return self._fetch(L.REC_CHAIN, 0, negval, 1.0, 0.0, 1.0, st.nnz)
+
+    def back_solve(self, prev_spread, dom_shape, negval=1e-8):
+        '''For each filter in prev_spread, convolute progressively in reverse order
+        (cuda_lib.py:145-221).  Returns coo matrices in order of emergence.'''
+        self._check_dom(dom_shape)
+        nf = len(prev_spread)
+        if nf == 0:
+            return []
+        rows, cols, vals, off = [], [], [], [0]
+        for B in prev_spread:
+            r, c, v, shape = _coo_arrays(B)
+            if shape != (self.dom_len, self.dom_len):
+                raise ValueError('back_solve filters must be dom_len x dom_len')
+            rows.append(r); cols.append(c); vals.append(v)
+            off.append(off[-1] + len(v))
+        row = L.i32(np.concatenate(rows)); col = L.i32(np.concatenate(cols))
+        val = L.f64(np.concatenate(vals)); off = np.ascontiguousarray(off, dtype=np.int64)
+        stats = (L.DayStats * nf)()
+        L.check(self._lib.ps_solver_back_solve(self._h, nf, L.p_i64(off), L.p_i32(row),
+                                               L.p_i32(col), L.p_f64(val), negval, 1.0, stats))
+        self.last_back_flags = [bool(s.flag) for s in stats]
+        return [self._fetch(L.REC_BACK, i, negval, 1.0, 0.0, 1.0, stats[i].nnz)
+                for i in range(nf)]
+
+    # ------------------------------------------------------ whole-chain API
+    def set_kernels(self, pmf_list):
+        '''Upload a list of odd-shaped sparse day kernels (prob_mass outputs).'''
+        rows, cols, vals, off, ks = [], [], [], [0], []
+        for B in pmf_list:
+            r, c, v, shape = _coo_arrays(B)
+            if shape[0] != shape[1]:
+                raise ValueError('kernel must be square, got {}'.format(shape))
+            rows.append(r); cols.append(c); vals.append(v)
+            off.append(off[-1] + len(v)); ks.append(shape[0])
+        cat = lambda xs, dt: np.ascontiguousarray(
+            np.concatenate(xs) if xs else np.zeros(0), dtype=dt)
+        row, col, val = cat(rows, np.int32), cat(cols, np.int32), cat(vals, np.float64)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        L.check(self._lib.ps_chain_set_kernels(self._h, len(ks), L.p_i64(off), L.p_i32(ks),
+                                               L.p_i32(row), L.p_i32(col), L.p_f64(val)))
+        self._nk = len(ks)
+
+    def run_chain(self, first=0, count=None, negval=1e-8, scale=1.0, renorm=True):
+        '''Enqueue days [first, first+count) of the uploaded kernels (no host sync).'''
+        count = self._nk - first if count is None else count
+        L.check(self._lib.ps_chain_run(self._h, first, count, negval, scale, int(bool(renorm))))
+
+    def chain_stats(self, first, count):
+        stats = (L.DayStats * count)()
+        L.check(self._lib.ps_chain_stats(self._h, first, count, stats))
+        return list(stats)
+
+    def chain_solution(self, day, stats, negval=1e-8, scale=1.0):
+        '''r_small_vals(A, prob_model=renorm) of chain day `day` as a coo matrix.'''
+        return self._fetch(L.REC_CHAIN, day, negval, scale, stats.delta, 1.0, stats.nnz)
+
+    def record_stats(self, kind, idx, negval=1e-8, scale=1.0, renorm=False):
+        st = L.DayStats()
+        L.check(self._lib.ps_record_stats(self._h, kind, idx, negval, scale, int(renorm),
+                                          C.byref(st)))
+        return st
+
+    def weighted_sum(self, kinds, idxs, weights):
+        k = L.i32(kinds); i = L.i32(idxs); w = L.f64(weights)
+        L.check(self._lib.ps_weighted_sum(self._h, len(w), L.p_i32(k), L.p_i32(i), L.p_f64(w)))
+
+    def dense(self, kind, idx):
+        out = np.empty((self.dom_len, self.dom_len))
+        L.check(self._lib.ps_record_fetch_dense(self._h, kind, idx, L.p_f64(out)))
+        return out
+
+    def sync(self):
+        L.check(self._lib.ps_solver_sync(self._h))
+
+    def get_spectrum(self):
+        P = self.fft_len
+        out = np.empty((P, P), dtype=np.complex128)
+        L.check(self._lib.ps_solver_get_spectrum(self._h, out.ctypes.data_as(L._F64P)))
+        return out
+
+    def set_spectrum(self, A_hat):
+        A_hat = np.ascontiguousarray(A_hat, dtype=np.complex128)
+        if A_hat.shape != (self.fft_len, self.fft_len):
+            raise ValueError('spectrum shape {} != pad shape'.format(A_hat.shape))
+        L.check(self._lib.ps_solver_set_spectrum(self._h, A_hat.ctypes.data_as(L._F64P)))
+
+    # -------------------------------------------------------------- helpers
+    def _check_dom(self, dom_shape):
+        if int(dom_shape[0]) != self.dom_len or int(dom_shape[1]) != self.dom_len:
+            raise ValueError('dom_shape {} != solver domain {}'.format(
+                tuple(dom_shape), self.dom_len))
+
+    def _fetch(self, kind, idx, negval, scale, delta, post, nnz_hint):
+        n = int(nnz_hint)
+        cap = max(n, 1)
+        while True:
+            row = np.empty(cap, dtype=np.int32)
+            col = np.empty(cap, dtype=np.int32)
+            val = np.empty(cap, dtype=np.float64)
+            nnz = C.c_int64()
+            rc = self._lib.ps_record_fetch_coo(self._h, kind, idx, negval, scale, delta, post,
+                                               L.p_i32(row), L.p_i32(col), L.p_f64(val), cap,
+                                               C.byref(nnz))
+            if rc == L.PS_ERR_BAD_ARG and nnz.value > cap:
+                cap = nnz.value
+                continue
+            L.check(rc)
+            n = nnz.value
+            return sparse.coo_matrix((val[:n], (row[:n], col[:n])),
+                                     shape=(self.dom_len, self.dom_len))

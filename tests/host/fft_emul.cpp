@@ -1,0 +1,117 @@
+// Host emulation of the in-LDS FFT program (parasitoids_amd/csrc/fft_core.h):
+// runs every stage thread by thread (wave-cooperative stages lane by lane with
+// "all lanes compute, then all lanes store") and compares against a long-double
+// DFT.  Usage: fft_emul L [L ...]   -> prints max relative error per case.
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <complex>
+#include "../../parasitoids_amd/csrc/fft_plan.h"
+
+typedef std::complex<long double> lc;
+
+static void naive(const std::vector<lc>& x, std::vector<lc>& y, int sign) {
+  int L = (int)x.size();
+  const long double twopi = 6.283185307179586476925286766559L;
+  std::vector<lc> w(L);
+  for (int t = 0; t < L; ++t) w[t] = lc(cosl(twopi * t / L), sign * sinl(twopi * t / L));
+  for (int k = 0; k < L; ++k) {
+    lc acc = 0;
+    for (int q = 0; q < L; ++q) acc += x[q] * w[(int)(((int64_t)q * k) % L)];
+    y[k] = acc;
+  }
+}
+
+template <int DIR>
+static void emul_stage(std::vector<cplx>& data, const HostFftPlan& hp, int s, int mode, int nb,
+                       int wsh, int bs, int nthr) {
+  const FftProg& P = hp.prog;
+  int r = P.radix[s];
+  bool spec = (r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 9);
+  if (spec) {
+    for (int tid = 0; tid < nthr; ++tid)
+      run_stage<DIR>(data.data(), hp.tw_lo.data(), hp.tw_hi.data(), P, s, mode, nb, wsh, bs, tid, nthr);
+  } else {
+    int nbutter = (P.L / r) * nb;
+    int G = r < 64 ? 64 / r : 1;
+    int nwaves = nthr / 64;
+    for (int wave = 0; wave < nwaves; ++wave)
+      for (int g0 = wave * G; g0 < nbutter; g0 += nwaves * G) {
+        std::vector<GenAcc> acc(64);
+        for (int lane = 0; lane < 64; ++lane)
+          gen_compute<DIR>(acc[lane], data.data(), hp.tw_lo.data(), hp.tw_hi.data(), P, s, mode, nb,
+                           wsh, bs, g0, lane);
+        for (int lane = 0; lane < 64; ++lane) gen_store(acc[lane], data.data(), r);
+      }
+  }
+}
+
+static double run_case(int L, int mode, int nb, int wsh, bool split) {
+  HostFftPlan hp;
+  if (!ps_build_plan(L, split, &hp)) { printf("plan failed L=%d\n", L); return -1; }
+  const FftProg& P = hp.prog;
+  int bs = row_pitch(P);
+  int W = 1 << wsh;
+  int nbatch = mode == PS_MODE_COL ? W : nb;
+  size_t ldsn = mode == PS_MODE_COL ? (size_t)L * W : (size_t)bs * nb;
+  std::vector<cplx> data(ldsn, make_double2(1e300, 1e300));
+  std::vector<std::vector<lc>> x(nbatch, std::vector<lc>(L)), y(nbatch, std::vector<lc>(L));
+  srand(L * 7 + mode);
+  auto addr = [&](int b, int i_logical) {
+    return mode == PS_MODE_COL ? (size_t)i_logical * W + b : (size_t)b * bs + row_phys(P, i_logical);
+  };
+  for (int b = 0; b < nbatch; ++b)
+    for (int i = 0; i < L; ++i) {
+      double re = rand() / (double)RAND_MAX - 0.5, im = rand() / (double)RAND_MAX - 0.5;
+      x[b][i] = lc(re, im);
+      data[addr(b, i)] = make_double2(re, im);
+    }
+  int nthr = 256;
+  int nbk = mode == PS_MODE_COL ? 1 : nb;
+  for (int s = 0; s < P.ns; ++s) emul_stage<PS_FWD>(data, hp, s, mode, mode == PS_MODE_COL ? W : nbk, wsh, bs, nthr);
+  double maxerr = 0, maxv = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    naive(x[b], y[b], -1);
+    for (int k = 0; k < L; ++k) {
+      cplx v = data[addr(b, hp.pos[k])];
+      if (mode == PS_MODE_ROW) {
+        cplx v2 = data[(size_t)b * bs + hp.pos_phys[k]];
+        if (v2.x != v.x || v2.y != v.y) { printf("pos_phys mismatch\n"); return -1; }
+      }
+      double e = (double)std::abs(lc(v.x, v.y) - y[b][k]);
+      maxerr = e > maxerr ? e : maxerr;
+      double a = (double)std::abs(y[b][k]);
+      maxv = a > maxv ? a : maxv;
+    }
+  }
+  double fwd = maxerr / maxv;
+  // inverse: run the inverse stages on the forward result; must return L * x
+  for (int s = P.ns - 1; s >= 0; --s) emul_stage<PS_INV>(data, hp, s, mode, mode == PS_MODE_COL ? W : nbk, wsh, bs, nthr);
+  double ierr = 0;
+  for (int b = 0; b < nbatch; ++b)
+    for (int i = 0; i < L; ++i) {
+      cplx v = data[addr(b, i)];
+      double e = (double)std::abs(lc(v.x, v.y) / (long double)L - x[b][i]);
+      ierr = e > ierr ? e : ierr;
+    }
+  printf("L=%d mode=%s nb=%d split=%d stages=", L, mode == PS_MODE_COL ? "col" : "row", nbatch, (int)split);
+  for (int s = 0; s < P.ns; ++s) printf("%d%s", P.radix[s], s + 1 == P.sa ? "|" : ".");
+  printf(" La=%d Lb=%d fwd_rel=%.3e inv_abs=%.3e\n", P.La, P.Lb, fwd, ierr);
+  return fwd > ierr ? fwd : ierr;
+}
+
+int main(int argc, char** argv) {
+  double worst = 0;
+  for (int a = 1; a < argc; ++a) {
+    int L = atoi(argv[a]);
+    double e1 = run_case(L, PS_MODE_COL, 1, 2, false);
+    double e2 = run_case(L, PS_MODE_ROW, 1, 0, true);
+    double e3 = run_case(L, PS_MODE_ROW, 2, 0, false);
+    for (double e : {e1, e2, e3}) {
+      if (e < 0) return 2;
+      worst = e > worst ? e : worst;
+    }
+  }
+  printf("WORST %.3e\n", worst);
+  return worst < 1e-13 ? 0 : 1;
+}

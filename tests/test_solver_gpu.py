@@ -1,0 +1,138 @@
+"""GPU parity tests of the day-chain solver (through the C ABI) against the oracle
+and the reference's golden vectors.  Mirrors the reference's own
+tests/test_CalcSol.py (test_cuda_convolve, test_cuda_back_solve) and adds the
+chain fixtures G6-G8.  Tolerances are fp64: 1e-12 absolute on probability
+fields (values <= 1), relative 1e-12 on population fields."""
+import numpy as np
+import pytest
+from scipy import signal, sparse
+
+from oracle import calcsol as OC
+from helpers import coo_from, recentre, assert_summary
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def hip_lib():
+    from parasitoids_amd import hip_lib
+    return hip_lib
+
+
+@pytest.fixture(scope='module')
+def two_arrays():
+    A = np.outer(range(10), range(1, 11))
+    B = np.outer(range(4, -1, -1), range(8, -1, -2))
+    return (A, B)
+
+
+@pytest.fixture(scope='module')
+def many_arrays(golden):
+    g = golden('g8_back_solve')
+    return tuple(g['toy_' + k] for k in 'ABCD')
+
+
+def test_hip_convolve(hip_lib, two_arrays):
+    '''reference tests/test_CalcSol.py:100-113 (test_cuda_convolve)'''
+    A, B = two_arrays
+    max_shape = np.array(A.shape) + 6
+    solver = hip_lib.HipSolve(sparse.coo_matrix(A), max_shape)
+    solver.fftconv2(sparse.csr_matrix(B))
+    C = solver.get_cursol(A.shape)
+    assert np.allclose(C.toarray(), signal.fftconvolve(A, B, 'same'), rtol=1e-12, atol=1e-10)
+    assert np.all(A == np.outer(range(10), range(1, 11)))
+    assert np.all(B == np.outer(range(4, -1, -1), range(8, -1, -2)))
+
+
+def test_hip_back_solve(hip_lib, many_arrays, golden):
+    '''reference tests/test_CalcSol.py:141-171 (test_cuda_back_solve), fp64 tolerance'''
+    A, B, C, D = many_arrays
+    solver = hip_lib.HipSolve(sparse.coo_matrix(C), A.shape)
+    solver.fftconv2(sparse.csr_matrix(D))
+    bck = solver.back_solve([sparse.csr_matrix(A), sparse.csr_matrix(B)], A.shape)
+    g = golden('g8_back_solve')
+    # the reference's CPU back_solve returns unthresholded fields; ours drops < 1e-8
+    for got, ref in ((bck[0], g['toy_bck0']), (bck[1], g['toy_bck1'])):
+        ref = np.where(ref < 1e-8, 0.0, ref)
+        np.testing.assert_allclose(got.toarray(), ref, rtol=0, atol=1e-11)
+
+
+def test_spectrum_roundtrip(hip_lib, two_arrays):
+    '''CalcSol.fft2 parity at the spectrum level (CalcSol.py:11-24)'''
+    A, B = two_arrays
+    solver = hip_lib.HipSolve(sparse.coo_matrix(A), B.shape)
+    ref = OC.fft2(sparse.coo_matrix(A), np.array(B.shape))
+    got = solver.get_spectrum()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10)
+    OC.fftconv2(ref, sparse.csr_matrix(B))
+    solver.fftconv2(sparse.csr_matrix(B))
+    np.testing.assert_allclose(solver.get_spectrum(), ref, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize('R,mode', [(128, 'exact'), (200, 'exact'), (128, 'fast'), (200, 'fast')])
+def test_get_solutions_chain(hip_lib, golden, R, mode):
+    '''G6: CalcSol.get_solutions on Kalbar kernels.  R=128: P=364=4*7*13 (no flags);
+    R=200: P=573=3*191 (generic radix, flags fire on 16 of 17 days).'''
+    g = golden('g6_solutions')
+    tag = 'r%d' % R
+    nd = int(g[tag + '_ndays'])
+    pmfs = [coo_from(g, '%s_pmf%d' % (tag, i)) for i in range(nd)]
+    ms = g[tag + '_max_shape']
+    N = 2 * R + 1
+    first = recentre(pmfs[0], R)
+    # oracle with the unthresholded states
+    trace = {}
+    modelsol = [first]
+    OC.get_solutions(modelsol, pmfs, list(range(nd)), nd, N, ms, trace=trace)
+
+    solver = hip_lib.HipSolve(first, ms, mode=mode)
+    assert solver.pad_shape == (N + ms[0] // 2, N + ms[1] // 2)
+    solver.set_kernels(pmfs[1:])
+    solver.run_chain(0, nd - 1, negval=1e-8, scale=1.0, renorm=True)
+    stats = solver.chain_stats(0, nd - 1)
+    tol = ATOL if mode == 'exact' else 5e-8   # fast mode: pad-region semantics differ
+    pos = g[tag + '_pos']
+    for n in range(nd - 1):
+        raw = solver.dense(0, n)
+        np.testing.assert_allclose(raw, trace['raw'][n], rtol=0, atol=tol)
+        np.testing.assert_allclose(raw[pos[:, 0], pos[:, 1]], g['%s_rawsamp%d' % (tag, n + 1)],
+                                   rtol=0, atol=tol)
+        if mode == 'exact':
+            assert bool(stats[n].flag) == bool(g[tag + '_flags'][n])
+            sol = solver.chain_solution(n, stats[n])
+            assert_summary(g, '%s_sum%d' % (tag, n + 1), sol, pos, rtol=1e-11, atol=1e-12,
+                           nnz_slack=2)
+            ref = modelsol[n + 1].tocsr()
+            assert abs(sol.tocsr() - ref).max() < 1e-12
+            assert abs(sol.sum() - 1.0) < 1e-12
+
+
+def test_get_cursol_matches_chain(hip_lib, golden):
+    '''per-call API (fftconv2 + get_cursol) == fused chain, bit for bit'''
+    g = golden('g6_solutions')
+    R, nd = 128, 4
+    pmfs = [coo_from(g, 'r128_pmf%d' % i) for i in range(nd)]
+    ms = g['r128_max_shape']
+    first = recentre(pmfs[0], R)
+    a = hip_lib.HipSolve(first, ms)
+    a.set_kernels(pmfs[1:])
+    a.run_chain(renorm=True)
+    b = hip_lib.HipSolve(first, ms)
+    for n in range(nd - 1):
+        b.fftconv2(pmfs[n + 1].tocsr())
+        sol = b.get_cursol([2 * R + 1] * 2)
+        ref = a.dense(0, n)
+        got = b.dense(0, 0)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-15)
+        assert sol.nnz == a.chain_stats(n, 1)[0].nnz
+
+
+def test_errors(hip_lib, two_arrays):
+    A, B = two_arrays
+    solver = hip_lib.HipSolve(sparse.coo_matrix(A), np.array(A.shape) + 6)
+    with pytest.raises(Exception):
+        solver.fftconv2(sparse.csr_matrix(np.ones((4, 4))))   # even kernel, CalcSol.py:58
+    with pytest.raises(ValueError):
+        solver.get_cursol((11, 11))
