@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grid-days/sec of the day-chain FFT convolution solver on a
+nominal 4096^2 fp64 domain (BASELINE.json metric, config 3).
+
+One "step" = one 30-day stack: state FFT, then per day  kernel scatter + forward
+FFT -> spectral product -> inverse FFT -> threshold statistics / boundary flag ->
+(flagged) truncate + re-FFT, all on the device with inputs (kernel COO triplets)
+resident in HBM.  N > 1: one process per GPU, every rank runs its own replica
+stack (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# algorithmic bytes per launch in units of P^2 (P = reference torus N + K//2), the
+# split of SURVEY 8d's W_day = 96 P^2 over this implementation's kernels
+ALG_P2 = {
+    'row_fwd': 16.0,     # kernel R2C row pass: 8 in + 8 out
+    'col_fwd_a': 8.0,    # forward column pass (16 P^2) split over two sub-pass launches
+    'col_fwd_b': 8.0,
+    'col_inv_a': 32.0,   # spectral product (24) + first half of the inverse column pass (8)
+    'col_inv_b': 8.0,
+    'row_inv': 24.0,     # inverse C2R row pass (16) + epilogue read of the real field (8)
+    'refft_pred': 0.0,   # flag-conditional re-FFT launches (40 P^2 per flagged day; no-ops here)
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rad-res', type=int, default=2048, help='R; domain N = 2R+1')
+    ap.add_argument('--kshape', type=int, default=2049)
+    ap.add_argument('--ndays', type=int, default=30)
+    ap.add_argument('--mode', default='fast', choices=['fast', 'exact'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-days', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(state, kernels, K, ndays_sample):
+    """Oracle (CPU restatement of CalcSol.get_solutions) on a bounded sample of the
+    same workload: state FFT + `ndays_sample` day steps, scipy.fft, one thread."""
+    from oracle import calcsol as OC
+    N = state.shape[0]
+    ms = np.array([K, K])
+    t0 = time.perf_counter()
+    hat = OC.fft2(state, ms)
+    t_init = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for n in range(ndays_sample):
+        OC.fftconv2(hat, kernels[n].tocsr())
+        A, flag = OC.ifft2(hat, [N, N])
+        OC.r_small_vals(A, prob_model=True)
+        if flag:
+            hat = OC.fft2(A, ms)
+    dt = time.perf_counter() - t0
+    return {'value': ndays_sample / dt, 'unit': 'grid-days/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d of the %d day steps of the same stack (oracle/calcsol.py, scipy.fft c2c '
+                      'at P=%d, 1 thread; state FFT %.1fs not counted)'
+                      % (ndays_sample, len(kernels), N + K // 2, t_init),
+            'host_cpus': os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['PARASITOID_DEVICE'] = str(local)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local))
+
+    from parasitoids_amd import hip_lib, synthetic
+
+    R, K, nd = args.rad_res, args.kshape, args.ndays
+    state, kernels, params = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613 + rank)
+    N = 2 * R + 1
+    P = N + K // 2
+    solver = hip_lib.HipSolve(state, [K, K], mode=args.mode, device=local)
+    solver.set_kernels(kernels)
+
+    def step():
+        solver.set_state(state)
+        solver.run_chain(0, nd, negval=1e-8, scale=1.0, renorm=True)
+
+    def fence():
+        solver.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # correctness guard outside the timed region: mass conserved, moments add up
+    stats = solver.chain_stats(0, nd)
+    raw = solver.dense(0, nd - 1)                 # unthresholded last-day field
+    idx = np.arange(N, dtype=np.float64)
+    s = raw.sum()
+    rowm = raw.sum(1)
+    mr = (rowm * idx).sum() / s
+    vr = (rowm * (idx - mr) ** 2).sum() / s
+    exp_mr = R + sum(synthetic.moments(k)[1] - K // 2 for k in kernels)
+    exp_vr = sum(synthetic.moments(k)[3] for k in kernels)
+    assert abs(s - 1.0) < 1e-9, s
+    assert abs(mr - exp_mr) < 1e-6 and abs(vr / exp_vr - 1) < 1e-7, (mr, exp_mr, vr, exp_vr)
+    assert abs(stats[-1].sum + stats[-1].delta * stats[-1].nnz - 1.0) < 1e-12
+    del raw
+
+    solver.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = solver.prof_read()
+    solver.prof_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        grid_days = world * args.steps * nd
+        value = grid_days / dt
+        kern = {}
+        for k, (ms, cnt) in prof.items():
+            if cnt:
+                avg = ms / cnt
+                alg = ALG_P2[k] * P * P
+                kern[k] = {'avg_ms': round(avg, 4), 'launches_per_step': cnt / args.steps,
+                           'alg_GBps': round(alg / (avg * 1e-3) / 1e9, 1)}
+        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['launches_per_step'])
+        ach = kern[dom]['alg_GBps']
+        out = {
+            'metric': 'grid-days/sec on 4096^2 fp64 domain',
+            'value': round(value, 3),
+            'unit': 'grid-days/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C3 synthetic stack: N=%d (nominal %d^2), %d Gaussian day kernels '
+                                   'K=%d, reference torus P=%d, FFT size %d (%s mode), prob model, '
+                                   'one replica stack per GPU' % (N, 2 * R, nd, K, P, solver.fft_len,
+                                                                  args.mode),
+                       'dom_len': N, 'ndays': nd, 'kshape': K, 'P': P, 'fft_len': solver.fft_len},
+            'alg_bytes_per_grid_day': 96.0 * P * P,
+            'alg_GBps_whole_chain': round(value / world * 96.0 * P * P / 1e9, 1),
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None},
+            'kernels': kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(state, kernels, K, args.cpu_days)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

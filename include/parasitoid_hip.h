@@ -128,6 +128,14 @@ int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out /* N*N */
 int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx,
                     const double* w);
 
+/* ---- measurement: HIP-event timing per kernel class on the handle's stream ----
+ * classes: 0 row_fwd, 1 col_fwd (first/single pass), 2 col_fwd (second sub-pass),
+ * 3 col_inv (first pass, fused spectral product), 4 col_inv (second), 5 row_inv+epilogue,
+ * 6 the three predicated passes of the flag-conditional re-FFT (no-ops when the flag is clear) */
+#define PS_PROF_NCLS 8
+int ps_prof_enable(ps_solver* s, int on);
+int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* count); /* synchronises */
+
 /* full P x P complex spectrum in/out (function-level CalcSol.fft2/fftconv2/ifft2 mirrors;
  * only valid in PS_MODE_EXACT) */
 int ps_solver_get_spectrum(ps_solver* s, double* out /* P*P*2 */);

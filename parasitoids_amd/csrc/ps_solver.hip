@@ -37,10 +37,14 @@ int ps_use_device(int device) {
 }
 
 static const int kMaxLds = 160 * 1024;
+#define PS_PROF_NCLS 8
+enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
+       PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6 };
 
 struct ColPass {
   DevPlan* plan;
   int n_outer, in_base_mul, in_stride, out_base_mul, out_stride, tw_mode;
+  bool second = false;  // second sub-pass of a split column transform
 };
 
 struct ps_solver {
@@ -82,6 +86,41 @@ struct ps_solver {
   DevBuf<const double*> wptr;
   DevBuf<double> wval;
   bool have_state = false;
+  // optional per-kernel-class HIP event timing (bench.py roofline leg)
+  bool prof_on = false;
+  struct ProfRec { int cls; hipEvent_t a, b; };
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[PS_PROF_NCLS] = {0};
+  long long prof_cnt[PS_PROF_NCLS] = {0};
+};
+
+static hipEvent_t prof_event(ps_solver* s) {
+  if (!s->prof_pool.empty()) {
+    hipEvent_t e = s->prof_pool.back();
+    s->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  ps_solver* s;
+  ps_solver::ProfRec r;
+  bool on;
+  ProfScope(ps_solver* s_, int cls) : s(s_), on(s_->prof_on) {
+    if (!on) return;
+    r.cls = cls;
+    r.a = prof_event(s);
+    r.b = prof_event(s);
+    (void)hipEventRecord(r.a, s->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s->stream);
+    s->prof_pending.push_back(r);
+  }
 };
 
 // ------------------------------------------------------------------ helpers
@@ -125,6 +164,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   const int thr = row_threads(a.prog.L);
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
+  ProfScope prof(s, pred ? PS_PROF_REFFT : PS_PROF_ROW_FWD);
   if (s->row_plan.generic)
     hipLaunchKernelGGL(k_row_fwd<true>, grid, dim3(thr), lds, s->stream, a);
   else
@@ -162,6 +202,8 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
     const int W2 = 1 << a.wsh;
     grid.x = (unsigned)(((s->H + W2 - 1) / W2) * cp.n_outer);
   }
+  ProfScope prof(s, pred ? PS_PROF_REFFT
+                          : (DIR == PS_FWD ? PS_PROF_COL_FWD_A : PS_PROF_COL_INV_A) + (cp.second ? 1 : 0));
   if (cp.plan->generic)
     hipLaunchKernelGGL((k_col<DIR, true>), grid, dim3(256), lds, s->stream, a);
   else
@@ -190,6 +232,7 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx) +
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
+  ProfScope prof(s, PS_PROF_ROW_INV);
   if (s->row_plan.generic)
     hipLaunchKernelGGL(k_row_inv<true>, grid, dim3(thr), lds, s->stream, a);
   else
@@ -303,9 +346,9 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     if ((rc = s->col_plan1.upload())) return fail(rc);
     if ((rc = s->col_plan2.upload())) return fail(rc);
     s->fwd_passes = {ColPass{&s->col_plan1, s->L2, 1, s->L2, 1, s->L2, 1},
-                     ColPass{&s->col_plan2, s->L1, s->L2, 1, 1, s->L1, 0}};
+                     ColPass{&s->col_plan2, s->L1, s->L2, 1, 1, s->L1, 0, true}};
     s->inv_passes = {ColPass{&s->col_plan2, s->L1, 1, s->L1, s->L2, 1, 0},
-                     ColPass{&s->col_plan1, s->L2, 1, s->L2, 1, s->L2, 2}};
+                     ColPass{&s->col_plan1, s->L2, 1, s->L2, 1, s->L2, 2, true}};
   } else {
     s->L2 = 1;
     if (!ps_build_plan(s->Pf, false, &s->col_plan1.host))
@@ -353,6 +396,8 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   s->rowsum.release(); s->rowcnt.release(); s->rowoff.release(); s->padmax.release();
   s->dstats.release(); s->flags.release();
   s->orow.release(); s->ocol.release(); s->oval.release(); s->wptr.release(); s->wval.release();
+  for (auto& r : s->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : s->prof_pool) (void)hipEventDestroy(e);
   delete s;
   return PS_OK;
 }
@@ -752,5 +797,41 @@ extern "C" int ps_solver_set_spectrum(ps_solver* s, const double* in) {
   tmp.release();
   if (e != hipSuccess) return ps_fail(PS_ERR_HIP, "set_spectrum: %s", hipGetErrorString(e));
   s->have_state = true;
+  return PS_OK;
+}
+
+// ----------------------------------------------------------------- profiling
+static int prof_drain(ps_solver* s) {
+  PS_HIP(hipStreamSynchronize(s->stream));
+  for (auto& r : s->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      s->prof_ms[r.cls] += ms;
+      s->prof_cnt[r.cls] += 1;
+    }
+    s->prof_pool.push_back(r.a);
+    s->prof_pool.push_back(r.b);
+  }
+  s->prof_pending.clear();
+  return PS_OK;
+}
+
+extern "C" int ps_prof_enable(ps_solver* s, int on) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(prof_drain(s));
+  for (int i = 0; i < PS_PROF_NCLS; ++i) { s->prof_ms[i] = 0; s->prof_cnt[i] = 0; }
+  s->prof_on = on != 0;
+  return PS_OK;
+}
+
+extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* count) {
+  if (!s || !total_ms || !count) return ps_fail(PS_ERR_BAD_ARG, "prof_read: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(prof_drain(s));
+  for (int i = 0; i < ncls; ++i) {
+    total_ms[i] = i < PS_PROF_NCLS ? s->prof_ms[i] : 0.0;
+    count[i] = i < PS_PROF_NCLS ? s->prof_cnt[i] : 0;
+  }
   return PS_OK;
 }

@@ -57,6 +57,15 @@ class HipSolve():
                                                   L.p_f64(val), len(val)))
         self._nk = 0
 
+    def set_state(self, A):
+        '''Replace the Fourier-space solution by fft2(A) (what the constructor does,
+        cuda_lib.py:34-54), keeping plans, buffers and uploaded kernels.'''
+        row, col, val, shape = _coo_arrays(A)
+        if shape != (self.dom_len, self.dom_len):
+            raise ValueError('state shape {} != solver domain'.format(shape))
+        L.check(self._lib.ps_solver_set_state_coo(self._h, L.p_i32(row), L.p_i32(col),
+                                                  L.p_f64(val), len(val)))
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             self._lib.ps_solver_destroy(self._h)
@@ -166,6 +175,21 @@ class HipSolve():
 
     def sync(self):
         L.check(self._lib.ps_solver_sync(self._h))
+
+    PROF_CLASSES = ('row_fwd', 'col_fwd_a', 'col_fwd_b', 'col_inv_a', 'col_inv_b', 'row_inv',
+                    'refft_pred')
+
+    def prof_enable(self, on=True):
+        '''HIP-event timing per kernel class on the solver's stream.'''
+        L.check(self._lib.ps_prof_enable(self._h, int(bool(on))))
+
+    def prof_read(self):
+        '''-> {class: (total_ms, launches)} (synchronises)'''
+        n = len(self.PROF_CLASSES)
+        ms = np.zeros(n)
+        cnt = np.zeros(n, dtype=np.int64)
+        L.check(self._lib.ps_prof_read(self._h, n, L.p_f64(ms), L.p_i64(cnt)))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
 
     def get_spectrum(self):
         P = self.fft_len
