@@ -164,6 +164,8 @@ int ps_model_fetch_coo(ps_model* m, int i, int32_t* row, int32_t* col, double* v
 /* diagnostics for tests: hprob[T] of day i of the last batch, stamp half-widths H[T] */
 int ps_model_fetch_debug(ps_model* m, int i, double* hprob, int32_t* Hs, double* loss,
                          double* pmfsum);
+/* h_flight_prob (ParasitoidModel.py:282-309) of wind row day_i: out[T] */
+int ps_model_hflight(ps_model* m, int day_i, const double* hparams, double* out);
 /* get_mvn_cdf_values (ParasitoidModel.py:311-380) for one (cell, mu, S): returns the
  * half width; fills out[(2H+1)^2] when cap allows. */
 int ps_model_mvn_cdf_values(ps_model* m, double cell, double mu_x, double mu_y, double sig_x,

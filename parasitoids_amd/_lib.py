@@ -82,6 +82,7 @@ SIGNATURES = {
                                      C.c_int, C.c_double, C.c_int, _I32P, _I64P, _I32P, _I32P]),
     'ps_model_fetch_coo': (C.c_int, [_VP, C.c_int, _I32P, _I32P, _F64P, C.c_int64]),
     'ps_model_fetch_debug': (C.c_int, [_VP, C.c_int, _F64P, _I32P, _F64P, _F64P]),
+    'ps_model_hflight': (C.c_int, [_VP, C.c_int, _F64P, _F64P]),
     'ps_model_mvn_cdf_values': (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_double, _I32P, _F64P, C.c_int64]),
     'ps_chain_set_kernels_from_model': (C.c_int, [_VP, _VP, C.c_int, C.c_int]),

@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 // dst[(row+roff)*ld + col+coff] += val   (duplicates sum, as coo.toarray() does)
-__global__ void k_scatter_coo(const int* __restrict__ row, const int* __restrict__ col,
+static __global__ void k_scatter_coo(const int* __restrict__ row, const int* __restrict__ col,
                               const double* __restrict__ val, int64_t nnz, double* dst, int ld,
                               int roff, int coff) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nnz;
@@ -24,7 +24,7 @@ struct DayStats {
 };
 
 // one block: reduce per-row statistics of one day in a fixed order
-__global__ void k_day_finalize(const double* rowsum, const long long* rowcnt,
+static __global__ void k_day_finalize(const double* rowsum, const long long* rowcnt,
                                const unsigned long long* padmax, int N, int renorm,
                                DayStats* out, int* flag_out) {
   __shared__ double ssum[256];
@@ -60,7 +60,7 @@ __global__ void k_day_finalize(const double* rowsum, const long long* rowcnt,
 
 // per-row statistics of a dense N x N field (used when a field was not produced
 // by the fused inverse-row epilogue, e.g. weighted sums and the first day)
-__global__ void k_row_stats(const double* __restrict__ rec, int N, double scale, double negval,
+static __global__ void k_row_stats(const double* __restrict__ rec, int N, double scale, double negval,
                             double* rowsum, long long* rowcnt) {
   __shared__ double ssum[256];
   __shared__ int scnt[256];
@@ -85,7 +85,7 @@ __global__ void k_row_stats(const double* __restrict__ rec, int N, double scale,
 }
 
 // exclusive scan of per-row counts (single block, N <= ~16k rows)
-__global__ void k_scan_rows(const long long* rowcnt, int N, long long* rowoff) {
+static __global__ void k_scan_rows(const long long* rowcnt, int N, long long* rowoff) {
   __shared__ long long part[1024];
   const int T = blockDim.x;
   const int per = (N + T - 1) / T;
@@ -104,7 +104,7 @@ __global__ void k_scan_rows(const long long* rowcnt, int N, long long* rowoff) {
 }
 
 // ordered compaction: one wave per row, row-major COO order like coo_matrix(dense)
-__global__ void k_compact_rows(const double* __restrict__ rec, int N, double scale, double negval,
+static __global__ void k_compact_rows(const double* __restrict__ rec, int N, double scale, double negval,
                                double delta, double post_scale, const long long* rowoff,
                                int* orow, int* ocol, double* oval) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -131,7 +131,7 @@ __global__ void k_compact_rows(const double* __restrict__ rec, int N, double sca
 }
 
 // out = sum_d w[d] * rec_d   (release-day weighted population, CalcSol.py:322)
-__global__ void k_weighted_sum(const double* const* recs, const double* w, int nrec, int64_t n,
+static __global__ void k_weighted_sum(const double* const* recs, const double* w, int nrec, int64_t n,
                                double* out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -143,7 +143,7 @@ __global__ void k_weighted_sum(const double* const* recs, const double* w, int n
 
 // Hermitian expansion of the half spectrum to a full P x P complex array
 // (only for the function-level CalcSol.fft2/fftconv2 mirrors)
-__global__ void k_expand_spectrum(const double2* __restrict__ half, int P, int H, int ld,
+static __global__ void k_expand_spectrum(const double2* __restrict__ half, int P, int H, int ld,
                                   double2* full) {
   const int64_t tot = (int64_t)P * P;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < tot;
@@ -161,7 +161,7 @@ __global__ void k_expand_spectrum(const double2* __restrict__ half, int P, int H
   }
 }
 
-__global__ void k_take_half_spectrum(const double2* __restrict__ full, int P, int H, int ld,
+static __global__ void k_take_half_spectrum(const double2* __restrict__ full, int P, int H, int ld,
                                      double2* half) {
   const int64_t tot = (int64_t)P * H;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < tot;

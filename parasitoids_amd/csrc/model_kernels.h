@@ -1,0 +1,568 @@
+// HIP kernels for the per-day probability-mass kernel construction
+// (ParasitoidModel.py:231-613).  fp64 VALU / transcendental bound, not HBM bound:
+// the work is ~(2H+2)^2 bivariate-normal corner evaluations per period, 1440
+// periods per day.
+//
+// Layout: one dense N x N fp64 pmf per day in HBM.  Each 16 x 16 output tile is
+// owned by one workgroup that walks the day's periods in order and adds
+// hprob[t] * mass (ParasitoidModel.py:539-540) -- a gather, so the accumulation
+// order is the reference's and results are reproducible run to run (no atomics).
+// Cell masses come from a shared (TS+1)^2 grid of BVU corner values in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PM_TS 16
+#define PM_MAX_NODES 10
+
+// Genz BVU quadrature data, precomputed on the host for the day's correlation
+struct BvuRule {
+  double r;                  // correlation
+  int lg;                    // number of node pairs (3, 6, 10)
+  int high;                  // |r| >= 0.925 branch
+  double w[PM_MAX_NODES];    // Gauss-Legendre weights
+  double x[PM_MAX_NODES];    // abscissae
+  double sn1[PM_MAX_NODES];  // sin(asr (x+1)/2)
+  double sn2[PM_MAX_NODES];  // sin(asr (-x+1)/2)
+  double asr;                // asin(r)
+};
+
+struct ModelParams {
+  double hp[7];     // lam, aw, bw, a1, b1, a2, b2
+  double sdx, sdy;  // flight diffusion std devs (sqrt of Dmat diagonal)
+  BvuRule rule;     // flight diffusion
+  double lsdx, lsdy;
+  BvuRule lrule;    // out-of-flow diffusion
+  double mu_r, rad_dist, cell;
+  int n_periods, rad_res, N, T, test_run, ndays_wind;
+};
+
+struct PeriodInfo {  // one per (day, period)
+  double mux, muy;   // residual mean, metres (ParasitoidModel.py:485)
+  double hprob;
+  int rc, cc, H;     // window centre (row, col) and half width
+  int skip;          // 1: t < start_indx
+};
+
+struct DayInfo {
+  double loss, pmfsum, total, delta, pmfmin, ksum;
+  long long nnz;
+  int rad, warned, status, start_indx, Hl, day_idx;
+  int r0, r1, c0, c1;  // bounding box of all windows, clipped to the domain
+};
+
+__device__ __forceinline__ double pm_phi(double z) {  // standard normal cdf
+  return 0.5 * erfc(-z * 0.70710678118654752440);
+}
+
+// P(X > h, Y > k), restating Genz's BVU (MVNDST) -- see oracle/model.py:bvu
+__device__ __forceinline__ double pm_bvu(const BvuRule& R, double h, double k) {
+  const double TWOPI = 6.283185307179586;
+  double hk = h * k;
+  double bvn = 0.0;
+  if (!R.high) {
+    const double hs = (h * h + k * k) / 2;
+    for (int i = 0; i < R.lg; ++i) {
+      double sn = R.sn1[i];
+      bvn = bvn + R.w[i] * exp((sn * hk - hs) / (1 - sn * sn));
+      sn = R.sn2[i];
+      bvn = bvn + R.w[i] * exp((sn * hk - hs) / (1 - sn * sn));
+    }
+    return bvn * R.asr / (2 * TWOPI) + pm_phi(-h) * pm_phi(-k);
+  }
+  const double r = R.r;
+  if (r < 0) {
+    k = -k;
+    hk = -hk;
+  }
+  if (fabs(r) < 1) {
+    const double as = (1 - r) * (1 + r);
+    double a = sqrt(as);
+    const double bs = (h - k) * (h - k);
+    const double c = (4 - hk) / 8;
+    const double d = (12 - hk) / 16;
+    bvn = a * exp(-(bs / as + hk) / 2) * (1 - c * (bs - as) * (1 - d * bs / 5) / 3 + c * d * as * as / 5);
+    if (hk > -160) {
+      const double b = sqrt(bs);
+      bvn = bvn - exp(-hk / 2) * sqrt(TWOPI) * pm_phi(-b / a) * b * (1 - c * bs * (1 - d * bs / 5) / 3);
+    }
+    a = a / 2;
+    for (int i = 0; i < R.lg; ++i) {
+      double xs = (a + a * R.x[i]) * (a + a * R.x[i]);
+      double rs = sqrt(1 - xs);
+      bvn = bvn + a * R.w[i] * (exp(-bs / (2 * xs) - hk / (1 + rs)) / rs -
+                                exp(-(bs / xs + hk) / 2) * (1 + c * xs * (1 + d * xs)));
+      xs = as * (-R.x[i] + 1) * (-R.x[i] + 1) / 4;
+      rs = sqrt(1 - xs);
+      bvn = bvn + a * R.w[i] * exp(-(bs / xs + hk) / 2) *
+                      (exp(-hk * (1 - rs) / (2 * (1 + rs))) / rs - (1 + c * xs * (1 + d * xs)));
+    }
+    bvn = -bvn / TWOPI;
+  }
+  if (r > 0) bvn = bvn + pm_phi(-fmax(h, k));
+  if (r < 0) bvn = -bvn + fmax(0.0, pm_phi(-h) - pm_phi(-k));
+  return bvn;
+}
+
+// rectangle probability of N(mu, S) on [xl,xu] x [yl,yu] as mvnun computes it
+__device__ __forceinline__ double pm_rect(const BvuRule& R, double sdx, double sdy, double mux,
+                                          double muy, double xl, double xu, double yl, double yu) {
+  const double l0 = (xl - mux) / sdx, u0 = (xu - mux) / sdx;
+  const double l1 = (yl - muy) / sdy, u1 = (yu - muy) / sdy;
+  return pm_bvu(R, l0, l1) - pm_bvu(R, u0, l1) - pm_bvu(R, l0, u1) + pm_bvu(R, u0, u1);
+}
+
+// support half width of get_mvn_cdf_values (ParasitoidModel.py:329,:348): smallest h
+// with 1 - P(square of half width (h + 1/2) cell) < 1e-3.  One wave, lanes try
+// h = base + lane.  The square probability equals the reference's running sum of
+// cell masses up to round-off ("support rule").
+__device__ __forceinline__ int pm_support(const BvuRule& R, double sdx, double sdy, double mux,
+                                          double muy, double cell, int hmax) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base <= hmax; base += 64) {
+    const int h = base + lane;
+    const double e = (h + 0.5) * cell;
+    const double p = pm_rect(R, sdx, sdy, mux, muy, -e, e, -e, e);
+    const bool ok = (h <= hmax) && (1 - p < 0.001);
+    const unsigned long long m = __ballot(ok);
+    if (m) return base + __ffsll((long long)m) - 1;
+  }
+  return hmax;
+}
+
+// ---------------------------------------------------------------- h_flight_prob
+// ParasitoidModel.py:282-309 with f_time_prob :243-267 and g_wind_prob :231-240.
+// One block per day; the two cumulative sums run sequentially like np.cumsum.
+__global__ void k_hprob(const double* __restrict__ wind, ModelParams mp, const int* day_idx,
+                        double* hprob /*[nd][T]*/, double* scratch /*[nd][3][T]*/) {
+  const int d = blockIdx.x;
+  const int n = mp.T;
+  const double* w = wind + (int64_t)day_idx[d] * n * 3;
+  double* f = scratch + (int64_t)d * 3 * n;
+  double* g = f + n;
+  double* c2 = g + n;
+  double* h = hprob + (int64_t)d * n;
+  const double lam = mp.hp[0], aw = mp.hp[1], bw = mp.hp[2], a1 = mp.hp[3], b1 = mp.hp[4],
+               a2 = mp.hp[5], b2 = mp.hp[6];
+  const double stop = 24 - 24. / n;
+  const double step = n > 1 ? stop / (n - 1) : 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double t = (i == n - 1 && n > 1) ? stop : i * step;
+    const double lik = fmax(1.0 / (1. + exp(-b1 * (t - a1))) - 1.0 / (1. + exp(-b2 * (t - a2))), 0.0);
+    f[i] = lik;
+    g[i] = 1.0 / (1. + exp(bw * (w[i * 3 + 2] - aw)));
+  }
+  __syncthreads();
+  __shared__ double s_max;
+  if (threadIdx.x == 0) {
+    // pairwise-free deterministic sum; numpy's pairwise sum differs by round-off only
+    double s = 0.0, mx = 0.0;
+    for (int i = 0; i < n; ++i) s += f[i];
+    for (int i = 0; i < n; ++i) {
+      f[i] = f[i] / s;
+      mx = fmax(mx, f[i]);
+    }
+    s_max = mx;
+    double c1 = 0.0, cc = 0.0;
+    for (int i = 0; i < n; ++i) {
+      c1 += f[i];
+      cc += (1 - c1) * (f[i] - f[i] * g[i]);
+      c2[i] = cc;
+    }
+  }
+  __syncthreads();
+  const double mx = s_max;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double fg = f[i] * g[i];
+    const double tv = (double)(i + 1);
+    const double integral_avg = fg / tv / mx * c2[i];
+    h[i] = lam * (fg + integral_avg);
+  }
+}
+
+// ---------------------------------------------------------------- per period
+// advection, residual mean, window centre, support (ParasitoidModel.py:439-499).
+// One wave per (day, period).
+__global__ void k_periods(const double* __restrict__ wind, const int* __restrict__ day_keys,
+                          ModelParams mp, const int* day_idx, const double* start_time,
+                          const double* hprob, PeriodInfo* pinfo) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int T = mp.T;
+  const int d = blockIdx.y;
+  if (wave >= T) return;
+  const int t = wave;
+  const int di = day_idx[d];
+  const double* dw = wind + (int64_t)di * T * 3;
+  PeriodInfo pi;
+  const double st = start_time[d];
+  const int start_indx = st < 0 ? 0 : (int)floor(st * T);
+  pi.skip = t < start_indx;
+  pi.hprob = hprob[(int64_t)d * T + t];
+  const int np_ = mp.n_periods;
+  double mx, my;
+  const bool has_next = (di + 1 < mp.ndays_wind) && (day_keys[di + 1] == day_keys[di] + 1);
+  if (!mp.test_run && np_ > 1) {
+    if (t + np_ - 1 < T) {
+      double sx = 0, sy = 0;
+      for (int i = t; i < t + np_; ++i) { sx += dw[i * 3]; sy += dw[i * 3 + 1]; }
+      mx = sx / np_;
+      my = sy / np_;
+    } else if (has_next) {
+      const double* nw = dw + (int64_t)T * 3;
+      double sx, sy;
+      if (t != T - 1) {
+        sx = 0; sy = 0;
+        for (int i = t; i < T; ++i) { sx += dw[i * 3]; sy += dw[i * 3 + 1]; }
+      } else {
+        sx = dw[(T - 1) * 3];
+        sy = dw[(T - 1) * 3 + 1];
+      }
+      const int wrap = np_ - (T - t);
+      if (wrap != 1) {
+        double ax = 0, ay = 0;
+        for (int i = 0; i < wrap; ++i) { ax += nw[i * 3]; ay += nw[i * 3 + 1]; }
+        sx += ax;
+        sy += ay;
+      } else {
+        sx += nw[0];
+        sy += nw[1];
+      }
+      mx = sx / np_;
+      my = sy / np_;
+    } else {
+      if (t != T - 1) {
+        double sx = 0, sy = 0;
+        for (int i = t; i < T; ++i) { sx += dw[i * 3]; sy += dw[i * 3 + 1]; }
+        mx = sx / (T - t);
+        my = sy / (T - t);
+      } else {
+        mx = dw[(T - 1) * 3];
+        my = dw[(T - 1) * 3 + 1];
+      }
+    }
+  } else if (!mp.test_run) {
+    mx = dw[t * 3];
+    my = dw[t * 3 + 1];
+  } else {
+    mx = dw[0];
+    my = dw[1];
+  }
+  const double fac = 86400.0 * ((double)np_ / (double)T);
+  mx = mx * fac; my = my * fac;
+  mx = mx * mp.mu_r; my = my * mp.mu_r;
+  const double c = mp.cell;
+  const double rx = rint(mx / c), ry = rint(my / c);
+  pi.mux = mx - rx * c;
+  pi.muy = my - ry * c;
+  pi.cc = mp.rad_res + (int)rint(mx / c);
+  pi.rc = mp.rad_res + (int)rint(-my / c);
+  pi.H = pi.skip ? 0 : pm_support(mp.rule, mp.sdx, mp.sdy, pi.mux, pi.muy, c, 4 * mp.rad_res + 64);
+  if ((threadIdx.x & 63) == 0) pinfo[(int64_t)d * T + t] = pi;
+}
+
+// per day: losses in period order (ParasitoidModel.py:541-558), hprob bounds
+// (:528-537), bounding box of the windows, local-stamp support.  One block per day.
+__global__ void k_day_prep(ModelParams mp, const double* start_time, const PeriodInfo* pinfo,
+                           DayInfo* dinfo, const int* day_idx) {
+  const int d = blockIdx.x;
+  const int T = mp.T, N = mp.N;
+  const PeriodInfo* pi = pinfo + (int64_t)d * T;
+  __shared__ int s_box[4];
+  __shared__ int s_hl;
+  if (threadIdx.x == 0) { s_box[0] = N; s_box[1] = -1; s_box[2] = N; s_box[3] = -1; }
+  __syncthreads();
+  int r0 = N, r1 = -1, c0 = N, c1 = -1;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    if (pi[t].skip) continue;
+    const int a0 = max(0, pi[t].rc - pi[t].H), a1 = min(N - 1, pi[t].rc + pi[t].H);
+    const int b0 = max(0, pi[t].cc - pi[t].H), b1 = min(N - 1, pi[t].cc + pi[t].H);
+    if (a0 <= a1 && b0 <= b1) {
+      r0 = min(r0, a0); r1 = max(r1, a1); c0 = min(c0, b0); c1 = max(c1, b1);
+    }
+  }
+  atomicMin(&s_box[0], r0); atomicMax(&s_box[1], r1);
+  atomicMin(&s_box[2], c0); atomicMax(&s_box[3], c1);
+  if (threadIdx.x < 64) {
+    const int hl = pm_support(mp.lrule, mp.lsdx, mp.lsdy, 0.0, 0.0, mp.cell, 4 * mp.rad_res + 64);
+    if (threadIdx.x == 0) s_hl = hl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DayInfo di;
+    di.status = 0; di.warned = 0;
+    di.loss = 0.0;
+    const double st = start_time[d];
+    di.start_indx = st < 0 ? 0 : (int)floor(st * T);
+    const double c = mp.cell;
+    for (int t = 0; t < T; ++t) {
+      if (pi[t].skip) continue;
+      const double hp = pi[t].hprob;
+      if (!(-1e-9 <= hp && hp <= 1.000000001)) { if (!di.status) di.status = -7; }
+      const int H = pi[t].H, rc = pi[t].rc, cc = pi[t].cc;
+      const int rmin = rc - H, rmax = rc + H, cmin = cc - H, cmax = cc + H;
+      // stamp index ranges kept after clipping (ParasitoidModel.py:508-527)
+      int rs = 0, re = 2 * H + 1, cs = 0, ce = 2 * H + 1;
+      if (rmax + 1 > N) re = max(0, re - (rmax + 1 - N));
+      if (cmax + 1 > N) ce = max(0, ce - (cmax + 1 - N));
+      if (rmin < 0) rs = -rmin;
+      if (cmin < 0) cs = -cmin;
+      const bool clipped = rs > 0 || re < 2 * H + 1 || cs > 0 || ce < 2 * H + 1;
+      const bool empty = rs >= re || cs >= ce;
+      if (empty) {
+        // wasps have left the domain (ParasitoidModel.py:547-558).  Python's negative
+        // slice stops make the reference raise (and warn) only for exits through
+        // the top / left edge.
+        if ((rmax <= -2 && rmax >= -N) || (cmax <= -2 && cmax >= -N)) di.warned = 1;
+        di.loss += hp;
+      } else if (clipped) {
+        // sum of the kept stamp cells == rectangle probability of the kept block
+        const double xl = (cs - H) * c - c / 2, xu = (ce - 1 - H) * c + c / 2;
+        const double yu = (H - rs) * c + c / 2, yl = (H - (re - 1)) * c - c / 2;
+        const double kept = pm_rect(mp.rule, mp.sdx, mp.sdy, pi[t].mux, pi[t].muy, xl, xu, yl, yu);
+        di.loss += (1 - kept) * hp;
+      }
+    }
+    di.r0 = s_box[0]; di.r1 = s_box[1]; di.c0 = s_box[2]; di.c1 = s_box[3];
+    di.Hl = s_hl;
+    di.pmfsum = 0; di.total = 0; di.delta = 0; di.pmfmin = 0; di.ksum = 0; di.nnz = 0; di.rad = 0;
+    di.day_idx = day_idx[d];
+    dinfo[d] = di;
+  }
+}
+
+// ---------------------------------------------------------------- accumulate
+// One workgroup per 16 x 16 pmf tile and day; periods in ascending order.
+__global__ void __launch_bounds__(256)
+k_stamp_tiles(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo* __restrict__ dinfo,
+              double* pmf /*[nd][N][N]*/) {
+  const int d = blockIdx.z;
+  const DayInfo& di = dinfo[d];
+  const int N = mp.N, T = mp.T;
+  const int i0 = blockIdx.y * PM_TS, j0 = blockIdx.x * PM_TS;
+  if (i0 > di.r1 || i0 + PM_TS - 1 < di.r0 || j0 > di.c1 || j0 + PM_TS - 1 < di.c0) return;
+  __shared__ double s_b[(PM_TS + 1) * (PM_TS + 1)];
+  const int tid = threadIdx.x;
+  const int li = tid / PM_TS, lj = tid % PM_TS;
+  const int i = i0 + li, j = j0 + lj;
+  const PeriodInfo* pi = pinfo + (int64_t)d * T;
+  const double c = mp.cell;
+  double acc = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const PeriodInfo p = pi[t];
+    if (p.skip) continue;
+    const int H = p.H;
+    // window / tile overlap (uniform across the block)
+    if (p.rc + H < i0 || p.rc - H > i0 + PM_TS - 1 || p.cc + H < j0 || p.cc - H > j0 + PM_TS - 1) continue;
+    // corner grid: x corners a = 0..TS at column j0+a, y corners b = 0..TS at row i0+b
+    for (int q = tid; q < (PM_TS + 1) * (PM_TS + 1); q += 256) {
+      const int b = q / (PM_TS + 1), a = q % (PM_TS + 1);
+      const double x = (j0 + a - p.cc) * c - c / 2;        // lower x edge of column j0+a
+      const double y = (p.rc - (i0 + b)) * c + c / 2;       // upper y edge of row i0+b
+      s_b[q] = pm_bvu(mp.rule, (x - p.mux) / mp.sdx, (y - p.muy) / mp.sdy);
+    }
+    __syncthreads();
+    const int ii = j - p.cc, jj = p.rc - i;
+    if (ii >= -H && ii <= H && jj >= -H && jj <= H && i < N && j < N) {
+      // cell [xl,xu] x [yl,yu]: BVU(xl,yl) - BVU(xu,yl) - BVU(xl,yu) + BVU(xu,yu)
+      const double ll = s_b[(li + 1) * (PM_TS + 1) + lj];
+      const double ul = s_b[(li + 1) * (PM_TS + 1) + lj + 1];
+      const double lu = s_b[li * (PM_TS + 1) + lj];
+      const double uu = s_b[li * (PM_TS + 1) + lj + 1];
+      const double mass = ((ll - ul) - lu) + uu;
+      acc = __dadd_rn(acc, __dmul_rn(p.hprob, mass));
+    }
+    __syncthreads();
+  }
+  if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
+}
+
+// sum and min of each day's pmf: partials per (day, block) then k_pmf_reduce2
+__global__ void k_pmf_reduce1(const double* __restrict__ pmf, int64_t n, double* psum, double* pmin) {
+  const int d = blockIdx.y;
+  const double* p = pmf + (int64_t)d * n;
+  double s = 0.0, m = 1e300;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = p[i];
+    s += v;
+    m = fmin(m, v);
+  }
+  __shared__ double ss[256], sm[256];
+  ss[threadIdx.x] = s; sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ss[threadIdx.x] += ss[threadIdx.x + off];
+      sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { psum[d * gridDim.x + blockIdx.x] = ss[0]; pmin[d * gridDim.x + blockIdx.x] = sm[0]; }
+}
+
+// per day: finish the reduction, assertion checks (ParasitoidModel.py:566-580), and the
+// non-flyer stamp around the origin (:581-599).  phase 0: first block; phase 1: after stamp.
+__global__ void k_day_local(ModelParams mp, const double* psum, const double* pmin, int nblk,
+                            DayInfo* dinfo, double* pmf, int phase) {
+  const int d = blockIdx.x;
+  DayInfo& di = dinfo[d];
+  __shared__ double s_sum, s_min;
+  if (threadIdx.x == 0) {
+    double s = 0.0, m = 1e300;
+    for (int b = 0; b < nblk; ++b) { s += psum[d * nblk + b]; m = fmin(m, pmin[d * nblk + b]); }
+    s_sum = s; s_min = m;
+  }
+  __syncthreads();
+  const double pmfsum = s_sum, pmfmin = s_min;
+  if (phase == 1) {
+    if (threadIdx.x == 0 && di.total < 0.99999 && !di.status) {
+      const double total2 = pmfsum + di.loss;
+      if (!(pmfmin >= -1e-8)) di.status = -8;
+      else if (!(total2 <= 1.00001)) di.status = -9;
+      di.pmfmin = pmfmin;
+    }
+    return;
+  }
+  __shared__ double s_total;
+  if (threadIdx.x == 0) {
+    di.pmfsum = pmfsum;
+    di.pmfmin = pmfmin;
+    di.total = pmfsum + di.loss;
+    if (!di.status) {
+      if (!(di.loss >= 0.0)) di.status = -9;
+      else if (!(pmfmin >= -1e-8)) di.status = -8;
+      else if (!(pmfsum <= 1.00001)) di.status = -9;
+    }
+    s_total = di.total;
+  }
+  __syncthreads();
+  const double total = s_total;
+  if (!(total < 0.99999)) return;
+  const int H = di.Hl, side = 2 * H + 1, R = mp.rad_res, N = mp.N;
+  const double c = mp.cell;
+  for (int q = threadIdx.x; q < side * side; q += blockDim.x) {
+    const int rho = q / side, kap = q % side;
+    const int ii = kap - H, jj = H - rho;
+    const double xl = ii * c - c / 2, yl = jj * c - c / 2;
+    const double mass = pm_rect(mp.lrule, mp.lsdx, mp.lsdy, 0.0, 0.0, xl, xl + c, yl, yl + c);
+    const int i = R - H + rho, j = R - H + kap;
+    if (i >= 0 && i < N && j >= 0 && j < N) {
+      double* cellp = pmf + ((int64_t)d * N + i) * N + j;
+      *cellp = __dadd_rn(*cellp, __dmul_rn(1 - total, mass));
+    }
+  }
+}
+
+// r_small_vals(prob_model=True) statistics + bounding radius (CalcSol.py:126-135,
+// ParasitoidModel.py:605-610): per row count, sum and max |j - R| of kept entries
+__global__ void k_pmf_row_stats(const double* __restrict__ pmf, int N, int R, double negval,
+                                double* rowsum, long long* rowcnt, int* rowrad) {
+  const int d = blockIdx.y, r = blockIdx.x;
+  const double* p = pmf + ((int64_t)d * N + r) * N;
+  double s = 0.0;
+  int c = 0, rad = -1;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const double t = p[j];
+    if (t != 0.0 && !(t < negval)) {
+      s += t;
+      ++c;
+      rad = max(rad, abs(j - R));
+    }
+  }
+  __shared__ double ss[256];
+  __shared__ int sc[256], sr[256];
+  ss[threadIdx.x] = s; sc[threadIdx.x] = c; sr[threadIdx.x] = rad;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ss[threadIdx.x] += ss[threadIdx.x + off];
+      sc[threadIdx.x] += sc[threadIdx.x + off];
+      sr[threadIdx.x] = max(sr[threadIdx.x], sr[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    rowsum[(int64_t)d * N + r] = ss[0];
+    rowcnt[(int64_t)d * N + r] = sc[0];
+    rowrad[(int64_t)d * N + r] = sc[0] > 0 ? max(sr[0], abs(r - R)) : -1;
+  }
+}
+
+__global__ void k_pmf_day_stats(const double* rowsum, const long long* rowcnt, const int* rowrad,
+                                int N, DayInfo* dinfo) {
+  const int d = blockIdx.x;
+  __shared__ double ss[256];
+  __shared__ long long sc[256];
+  __shared__ int sr[256];
+  double s = 0.0;
+  long long c = 0;
+  int rad = -1;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    s += rowsum[(int64_t)d * N + r];
+    c += rowcnt[(int64_t)d * N + r];
+    rad = max(rad, rowrad[(int64_t)d * N + r]);
+  }
+  ss[threadIdx.x] = s; sc[threadIdx.x] = c; sr[threadIdx.x] = rad;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ss[threadIdx.x] += ss[threadIdx.x + off];
+      sc[threadIdx.x] += sc[threadIdx.x + off];
+      sr[threadIdx.x] = max(sr[threadIdx.x], sr[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    DayInfo& di = dinfo[d];
+    di.nnz = sc[0];
+    di.ksum = ss[0];
+    di.delta = sc[0] > 0 ? (1 - ss[0]) / (double)sc[0] : 0.0;
+    di.rad = sr[0];
+    if (!di.status && sc[0] == 0) di.status = -11;
+  }
+}
+
+// ordered compaction of one day's pmf into COO with the shrink offset (:611-613)
+__global__ void k_pmf_compact(const double* __restrict__ pmf, int N, double negval, double delta,
+                              int idx_off, const long long* rowoff, int* orow, int* ocol, double* oval) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= N) return;
+  long long base = rowoff[wave];
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int c = c0 + lane;
+    double t = 0.0;
+    bool keep = false;
+    if (c < N) {
+      t = pmf[(int64_t)wave * N + c];
+      keep = (t != 0.0) && !(t < negval);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int o = __popcll(m & ((1ull << lane) - 1ull));
+      orow[base + o] = wave + idx_off;
+      ocol[base + o] = c + idx_off;
+      oval[base + o] = t + delta;
+    }
+    base += __popcll(m);
+  }
+}
+
+// get_mvn_cdf_values (ParasitoidModel.py:311-380) for one (cell, mu, S)
+__global__ void k_mvn_cdf_values(BvuRule rule, double sdx, double sdy, double mux, double muy,
+                                 double cell, int hmax, int* Hout, double* out, long long cap) {
+  __shared__ int s_h;
+  if (threadIdx.x < 64) {
+    const int h = pm_support(rule, sdx, sdy, mux, muy, cell, hmax);
+    if (threadIdx.x == 0) s_h = h;
+  }
+  __syncthreads();
+  const int H = s_h, side = 2 * H + 1;
+  if (threadIdx.x == 0) *Hout = H;
+  if ((long long)side * side > cap) return;
+  for (int q = threadIdx.x; q < side * side; q += blockDim.x) {
+    const int rho = q / side, kap = q % side;
+    const int ii = kap - H, jj = H - rho;
+    const double xl = ii * cell - cell / 2, yl = jj * cell - cell / 2;
+    out[q] = pm_rect(rule, sdx, sdy, mux, muy, xl, xl + cell, yl, yl + cell);
+  }
+}

@@ -97,3 +97,11 @@ struct DevPlan {
 };
 
 int ps_use_device(int device);
+
+// internal cross-module entry points (solver <-> model, same shared library)
+int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                                  const int* row, const int* col, const double* val);
+int ps_solver_set_state_device_coo(ps_solver* s, const int* row, const int* col, const double* val,
+                                   int64_t nnz, int off);
+int ps_solver_dom_len_internal(ps_solver* s);
+int ps_solver_device_internal(ps_solver* s);

@@ -835,3 +835,6 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
   }
   return PS_OK;
 }
+
+int ps_solver_dom_len_internal(ps_solver* s) { return s->N; }
+int ps_solver_device_internal(ps_solver* s) { return s->device; }

@@ -1,0 +1,71 @@
+"""CPU tests of the host-side logic of the product package: wind I/O (bit-exact
+against the reference's golden arrays), the C-ABI library (loads, exports every
+declared symbol), FFT program emulation, parameter handling."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wind_interpolation_bit_exact(golden, golden_dir):
+    from parasitoids_amd import ParasitoidModel as PM
+    g = golden('g3_hprob_wind')
+    for site, st in (('kalbar', '00:00'), ('carnarvonearl', '00:30')):
+        wd, days = PM.get_wind_data(os.path.join(golden_dir, 'data', site), 30, st)
+        assert list(g[site + '_days']) == days
+        assert np.array_equal(np.array([wd[d].sum(0) for d in days]), g[site + '_wind_sum'])
+        assert np.array_equal(wd[days[0]], g[site + '_wind_first'])
+        assert np.array_equal(wd[days[-1]], g[site + '_wind_last'])
+        assert np.array_equal(wd[days[3]], g[site + '_wind_mid'])
+        # reference test_get_wind_data properties (tests/test_ParsitoidModel.py:117-143)
+        raw, days_raw = PM.read_wind_file(os.path.join(golden_dir, 'data', site))
+        assert days_raw == days
+        assert wd[days[0]].shape[0] == 30 * raw[days[0]].shape[0]
+        for key in raw:
+            assert np.all(np.sqrt(wd[key][:, 0]**2 + wd[key][:, 1]**2) == wd[key][:, 2])
+    with pytest.raises(ValueError):
+        PM.get_wind_data(os.path.join(golden_dir, 'data', 'kalbar'), 30, '01:00')
+
+
+def test_library_exports_every_declared_symbol():
+    from parasitoids_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'parasitoid_hip.h')).read()
+    declared = set(re.findall(r'\b(ps_[a-z0-9_]+)\s*\(', header))
+    declared -= {'ps_day_stats'}
+    assert declared, 'no declarations parsed'
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'missing export ' + name
+        assert name in _lib.SIGNATURES, 'no ctypes signature for ' + name
+    assert lib.ps_version() >= 100
+
+
+def test_no_gpu_is_import_error():
+    """Without a GPU the device modules must fail loudly (ImportError), never fall back."""
+    from parasitoids_amd import _lib
+    lib = _lib.load()
+    if lib.ps_device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(ImportError):
+        import parasitoids_amd.hip_lib  # noqa: F401
+    from parasitoids_amd import ParasitoidModel as PM
+    with pytest.raises(ImportError):
+        PM.prob_mass(1, {1: np.zeros((48, 3))}, (1,) * 7, (1, 1, 0), (1, 1, 0), 1, 1, 100.0, 4)
+
+
+def test_fft_program_emulation():
+    """The in-LDS FFT program (fft_core.h), emulated thread by thread on the host,
+    against a long-double DFT: all register radices, generic primes, both layouts."""
+    exe = os.path.join(ROOT, 'tests', 'host', '_build', 'fft_emul')
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(['g++', '-O2', '-std=c++17', '-o', exe,
+                    os.path.join(ROOT, 'tests', 'host', 'fft_emul.cpp')], check=True)
+    out = subprocess.run([exe, '1', '2', '3', '5', '7', '8', '9', '16', '72', '82', '364', '573',
+                          '1121', '1155', '2592'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    worst = float(out.stdout.strip().split()[-1])
+    assert worst < 5e-15
