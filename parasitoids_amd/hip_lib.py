@@ -89,7 +89,7 @@ class HipSolve():
         L.check(self._lib.ps_solver_fftconv2_coo(self._h, L.p_i32(row), L.p_i32(col),
                                                  L.p_f64(val), len(val), int(shape[0])))
 
-    def get_cursol(self, dom_shape, negval=1e-8):
+    def get_cursol(self, dom_shape, negval=1e-8, fetch=True):
         '''Return the current solution (requires ifft) with small values removed
         (cuda_lib.py:98-140); re-transforms the truncated solution when mass has
         reached the pad region.
@@ -100,9 +100,11 @@ class HipSolve():
         st = L.DayStats()
         L.check(self._lib.ps_solver_get_cursol(self._h, negval, 1.0, 0, C.byref(st)))
         self.last_flag = bool(st.flag)
+        if not fetch:       # leave the field on the device (record PS_REC_CHAIN,0)
+            return None
         return self._fetch(L.REC_CHAIN, 0, negval, 1.0, 0.0, 1.0, st.nnz)
 
-    def back_solve(self, prev_spread, dom_shape, negval=1e-8):
+    def back_solve(self, prev_spread, dom_shape, negval=1e-8, fetch=True):
         '''For each filter in prev_spread, convolute progressively in reverse order
         (cuda_lib.py:145-221).  Returns coo matrices in order of emergence.'''
         self._check_dom(dom_shape)
@@ -122,6 +124,8 @@ class HipSolve():
         L.check(self._lib.ps_solver_back_solve(self._h, nf, L.p_i64(off), L.p_i32(row),
                                                L.p_i32(col), L.p_f64(val), negval, 1.0, stats))
         self.last_back_flags = [bool(s.flag) for s in stats]
+        if not fetch:       # leave the fields on the device (records PS_REC_BACK,i)
+            return None
         return [self._fetch(L.REC_BACK, i, negval, 1.0, 0.0, 1.0, stats[i].nnz)
                 for i in range(nf)]
 

@@ -1,0 +1,155 @@
+"""GPU tests of the CalcSol / Run mirrors: the reference's own tests/test_CalcSol.py
+(test_fftconv2, test_convolve_same, test_back_solve) re-run against the device functions,
+and end-to-end runs (wind file -> device prob_mass -> device chain) against G6/G7/G8."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse, signal, fft as sfft
+
+from helpers import coo_from, assert_summary
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def CS():
+    from parasitoids_amd import CalcSol
+    return CalcSol
+
+
+@pytest.fixture(scope='module')
+def two_arrays():
+    A = np.outer(range(10), range(1, 11))
+    B = np.outer(range(4, -1, -1), range(8, -1, -2))
+    return (A, B)
+
+
+def test_fftconv2(CS, two_arrays):
+    '''reference tests/test_CalcSol.py:75-83'''
+    A, B = two_arrays
+    A_hat = CS.fft2(sparse.coo_matrix(A), np.array(B.shape))
+    before = A_hat.copy()
+    CS.fftconv2(A_hat, sparse.csr_matrix(B))
+    assert not np.all(A_hat == before)
+    assert np.all(B == np.outer(range(4, -1, -1), range(8, -1, -2)))
+    assert np.allclose(sfft.ifft2(A_hat)[:A.shape[0], :A.shape[1]].real,
+                       signal.convolve2d(A, B, 'same'))
+
+
+def test_convolve_same(CS, two_arrays):
+    '''reference tests/test_CalcSol.py:85-98'''
+    A, B = two_arrays
+    fft_shape = np.array([A.shape[0] + 6, A.shape[1] + 6])
+    A_hat = CS.fft2(sparse.coo_matrix(A), fft_shape)
+    CS.fftconv2(A_hat, sparse.csr_matrix(B))
+    C, flag = CS.ifft2(A_hat, A.shape)
+    C = C.toarray()
+    assert not np.iscomplexobj(C)
+    assert np.allclose(C, signal.fftconvolve(A, B, 'same'))
+
+
+def test_back_solve(CS, golden):
+    '''reference tests/test_CalcSol.py:115-139'''
+    g = golden('g8_back_solve')
+    A, B, C, D = (g['toy_' + k] for k in 'ABCD')
+    C_hat = CS.fft2(sparse.coo_matrix(C), A.shape)
+    CS.fftconv2(C_hat, sparse.csr_matrix(D))
+    bckCD = CS.back_solve([sparse.csr_matrix(A), sparse.csr_matrix(B)], C_hat, A.shape)
+    B_hat = CS.fft2(sparse.coo_matrix(B), A.shape)
+    CS.fftconv2(B_hat, sparse.csr_matrix(C))
+    CS.fftconv2(B_hat, sparse.csr_matrix(D))
+    BCD, flag = CS.ifft2(B_hat, B.shape)
+    A_hat = CS.fft2(sparse.coo_matrix(A), A.shape)
+    for X in (B, C, D):
+        CS.fftconv2(A_hat, sparse.csr_matrix(X))
+    ABCD, flag = CS.ifft2(A_hat, A.shape)
+    assert np.allclose(bckCD[1].toarray(), BCD.toarray())
+    assert np.allclose(bckCD[0].toarray(), ABCD.toarray())
+    np.testing.assert_allclose(bckCD[0].toarray(), g['toy_bck0'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(bckCD[1].toarray(), g['toy_bck1'], rtol=0, atol=1e-11)
+
+
+def test_r_small_vals(CS):
+    rng = np.random.default_rng(3)
+    A = rng.random((40, 40)) * (rng.random((40, 40)) < 0.3)
+    A[A < 0.05] *= 1e-9
+    A /= A.sum()
+    got = CS.r_small_vals(sparse.coo_matrix(A), prob_model=True)
+    keep = A >= 1e-8
+    ref = np.where(keep, A, 0.0)
+    ref[keep] += (1 - ref.sum()) / keep.sum()
+    np.testing.assert_allclose(got.toarray(), ref, rtol=0, atol=1e-16)
+    assert got.nnz == keep.sum()
+    got2 = CS.r_small_vals(sparse.coo_matrix(A))
+    np.testing.assert_allclose(got2.toarray(), np.where(keep, A, 0.0), rtol=0, atol=0)
+
+
+def _params(golden_dir, *args):
+    from parasitoids_amd import Run
+    p = Run.Params(config=None)
+    p.cmd_line_chg(list(args))
+    p.site_name = os.path.join(golden_dir, p.site_name)
+    p.OUTPUT = False
+    return Run, p
+
+
+def test_run_config1_prob_model(golden, golden_dir):
+    '''C1 / G6: Run.py --prob --kalbar ndays=6 domain_info=(10000.0,128), end to end on the
+    device, against the reference's CPU solutions.'''
+    Run, p = _params(golden_dir, '--kalbar', '--prob', 'ndays=6', 'domain_info=(10000.0,128)')
+    modelsol, days, ndays, _ = Run.run_model(p, verbose=False)
+    g = golden('g6_solutions')
+    assert ndays == 6 and days[:6] == [13, 14, 15, 16, 17, 18]
+    pos = g['r128_pos']
+    for i, s in enumerate(modelsol):
+        ref = coo_from(g, 'r128_sol%d' % i).tocsr()
+        assert abs(s.tocsr() - ref).max() < 1e-12
+        assert abs(s.sum() - 1.0) < 1e-12
+        assert_summary(g, 'r128_sum%d' % i, s, pos, rtol=1e-10, atol=1e-12, nnz_slack=3)
+
+
+def test_run_pop_model_kalbar(golden, golden_dir):
+    '''G7: --pop --kalbar (r_dur=1), R=128, 6 days'''
+    Run, p = _params(golden_dir, '--kalbar', '--pop', 'ndays=6', 'domain_info=(10000.0,128)')
+    modelsol, days, ndays, _ = Run.run_model(p, verbose=False)
+    g = golden('g7_populations')
+    pos = g['r128_pos']
+    for i, s in enumerate(modelsol):
+        ref = coo_from(g, 'r128_pop%d' % i).tocsr()
+        assert abs(s.tocsr() - ref).max() < 1e-7          # values up to 1.3e5 (rel 1e-12)
+        assert_summary(g, 'r128_sum%d' % i, s, pos, rtol=1e-10, atol=1e-7, nnz_slack=3)
+
+
+def test_run_pop_model_carnarvon_rdur5(golden, golden_dir):
+    '''G8: --pop --carnarvon r_dur=5 at domain_info=(40000.0,200), 30 days: multi-day
+    release with back_solve and the release-day weighted sums'''
+    Run, p = _params(golden_dir, '--carnarvon', '--pop', 'domain_info=(40000.0,200)')
+    assert p.r_dur == 5 and p.r_number == 40000 and p.r_start == 0.354
+    modelsol, days, ndays, _ = Run.run_model(p, verbose=False)
+    g = golden('g8_back_solve')
+    assert ndays == 30
+    pos = g['car_pos']
+    for i, s in enumerate(modelsol):
+        assert_summary(g, 'car_sum%d' % i, s, pos, rtol=1e-9, atol=1e-7, nnz_slack=4)
+    for i in (0, 4, 5, 29):
+        ref = coo_from(g, 'car_pop%d' % i).tocsr()
+        assert abs(modelsol[i].tocsr() - ref).max() < 1e-7
+
+
+def test_save_result_format(golden_dir, tmp_path):
+    '''on-disk format of Run.py:490-516 (read back like Plot_Result.py:511-524)'''
+    Run, p = _params(golden_dir, '--kalbar', '--prob', 'ndays=2', 'domain_info=(10000.0,64)')
+    p.outfile = str(tmp_path / 'out' / 'kalbar_test')
+    modelsol, days, ndays, _ = Run.run_model(p, verbose=False)
+    Run.save_result(p, modelsol, days, ndays)
+    z = np.load(p.outfile + '.npz')
+    assert list(z['days']) == days[:2]
+    dom = 129
+    for n, day in enumerate(days[:2]):
+        m = sparse.csr_matrix((z[str(day) + '_data'], z[str(day) + '_ind'],
+                               z[str(day) + '_indptr']), shape=(dom, dom))
+        assert abs(m - modelsol[n].tocsr()).max() == 0
+    q = Run.Params(config=None)
+    q.file_read_chg(p.outfile)
+    assert tuple(q.domain_info) == (10000.0, 64) and q.ndays == 2

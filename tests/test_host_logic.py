@@ -69,3 +69,36 @@ def test_fft_program_emulation():
     assert out.returncode == 0, out.stdout[-2000:]
     worst = float(out.stdout.strip().split()[-1])
     assert worst < 5e-15
+
+
+def test_params_defaults_and_parsing(tmp_path):
+    """Run.Params: defaults (reference Run.py:47-91), presets (:96-138), tuple orders
+    (:374-384), command line / config handling (:218-352) incl. the reference's quirks."""
+    from parasitoids_amd.Run import Params
+    p = Params(config=None)
+    assert p.dataset == 'kalbar' and p.site_name == 'data/kalbar' and p.start_time == '00:00'
+    assert p.r_dur == 1 and p.r_number == 130000 and p.r_start is None
+    assert p.domain_info == (10000.0, 400) and p.interp_num == 30 and p.n_periods == 30
+    hparams, Dp, Dl, mu_r, npd, rad_dist, rad_res = p.get_model_params()
+    assert hparams == (1., 1.263, 3.913, 7.302, 2.614, 23.999, 2.350)
+    assert Dp == (171.82, 144.58, 0.253) and Dl == (7.096, 7.260, 0.000)
+    assert (mu_r, npd, rad_dist, rad_res) == (1.179, 30, 10000.0, 400)
+    assert p.get_wind_params() == ('data/kalbar', 30, '00:00')
+    p.cmd_line_chg(['--carnarvon', '--pop', 'r_dur=1', 'domain_info=(8000.0,320)', 'ndays=3',
+                    'Dparams=(4.0, 4.0, 0.)', 'r_number=7', '--no_output', 'cuda=False'])
+    assert p.site_name == 'data/carnarvonearl' and p.start_time == '00:30'
+    assert p.PROB_MODEL is False and p.r_dur == 1 and p.r_start == 0.354
+    assert p.r_number == 40000                      # reference Run.py:294-295 never assigns it
+    assert p.domain_info == (8000.0, 320) and p.ndays == 3 and p.Dparams == (4.0, 4.0, 0.0)
+    assert p.OUTPUT is False and p.CUDA is False and '_pop' in p.outfile
+    assert p.uniform(1) == 1.0 and p.r_mthd() == p.uniform
+    with pytest.raises(ValueError):
+        p.cmd_line_chg(['--bogus'])
+    with pytest.raises(LookupError):
+        p.cmd_line_chg(['bogus=1'])
+    with pytest.raises(ValueError):
+        p.cmd_line_chg(['ndays=abc'])
+    cfg = tmp_path / 'config.txt'
+    cfg.write_text('# local configuration\ndataset = carnarvon  # preset\nmu_r = 2.5\nplot = False\n')
+    q = Params(config=str(cfg))
+    assert q.dataset == 'carnarvon' and q.r_dur == 5 and q.mu_r == 2.5 and q.PLOT is False
