@@ -42,9 +42,12 @@ struct FftProg {
   int32_t radix[PS_MAX_STAGES];
   int32_t n[PS_MAX_STAGES];  // block length entering stage s
   int32_t m[PS_MAX_STAGES];  // n / radix
+  int32_t step[PS_MAX_STAGES];  // L / n: twiddle stride of the stage
   // row-mode LDS layout: logical index i lives at (i / Lb) * Lbp + i % Lb.
   // stages [0,sa) have m % Lb == 0 ("leading"), stages [sa,ns) have n <= Lb.
   int32_t sa, La, Lb, Lbp;
+  // multiply-shift reciprocals (ps_magic) of the divisors used by bf_decode
+  uint32_t mg_m[PS_MAX_STAGES], mg_mh[PS_MAX_STAGES], mg_nbf[PS_MAX_STAGES], mg_Lb, mg_La;
   int32_t tw_shift, n_lo, n_hi;  // w_L^t = tw_hi[t >> shift] * tw_lo[t & mask]
   const cplx* tw_lo;             // device
   const cplx* tw_hi;             // device
@@ -243,6 +246,17 @@ PS_HD cplx tw_lookup(const cplx* tlo, const cplx* thi, int shift, int t) {
   return cmul(thi[t >> shift], tlo[t & ((1 << shift) - 1)]);
 }
 
+// ------------------------------------------------------------- fast division
+// q = x / d for 0 <= x < 2^32 / d via one 32x32->hi multiply; d == 1 has magic 0.
+PS_HD uint32_t ps_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+PS_HD int ps_div(int x, uint32_t mg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return mg ? (int)__umulhi((uint32_t)x, mg) : x;
+#else
+  return mg ? (int)(((uint64_t)(uint32_t)x * mg) >> 32) : x;
+#endif
+}
+
 // ------------------------------------------------------ butterfly addressing
 // mode COL: LDS holds a [L][W] tile (W = 1 << wsh columns, the batch), FFT along
 //           the rows; lanes run along the batch.
@@ -262,26 +276,29 @@ PS_HD BfAddr bf_decode(const FftProg& P, int s, int mode, int item, int wsh, int
   if (mode == PS_MODE_COL) {
     const int b = item & ((1 << wsh) - 1);
     const int bf = item >> wsh;
-    const int j = bf % m, blk = bf / m;
+    const int blk = ps_div(bf, P.mg_m[s]);
+    const int j = bf - blk * m;
     a.addr0 = ((blk * n + j) << wsh) + b;
     a.qstride = m << wsh;
     a.j = j;
   } else {
-    const int nbf = P.L / P.radix[s];
-    const int b = item / nbf;
+    const int nbf = m * (P.L / n);
+    const int b = ps_div(item, P.mg_nbf[s]);
     const int bf = item - b * nbf;
     if (s < P.sa) {
-      const int mh = m / P.Lb;
-      const int j_lo = bf % P.Lb;
-      const int t = bf / P.Lb;
-      const int j_hi = t % mh, blk = t / mh;
-      a.addr0 = b * bs + (blk * (n / P.Lb) + j_hi) * P.Lbp + j_lo;
+      const int mh = ps_div(m, P.mg_Lb);
+      const int t = ps_div(bf, P.mg_Lb);
+      const int j_lo = bf - t * P.Lb;
+      const int blk = ps_div(t, P.mg_mh[s]);
+      const int j_hi = t - blk * mh;
+      a.addr0 = b * bs + (blk * ps_div(n, P.mg_Lb) + j_hi) * P.Lbp + j_lo;
       a.qstride = mh * P.Lbp;
       a.j = j_hi * P.Lb + j_lo;
     } else {
-      const int rho = bf % P.La;
-      const int inner = bf / P.La;
-      const int j = inner % m, sub = inner / m;
+      const int inner = ps_div(bf, P.mg_La);
+      const int rho = bf - inner * P.La;
+      const int sub = ps_div(inner, P.mg_m[s]);
+      const int j = inner - sub * m;
       a.addr0 = b * bs + rho * P.Lbp + sub * n + j;
       a.qstride = m;
       a.j = j;
@@ -294,8 +311,8 @@ PS_HD BfAddr bf_decode(const FftProg& P, int s, int mode, int item, int wsh, int
 template <int R, int DIR>
 PS_HD void run_stage_r(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P,
                        int s, int mode, int nb, int wsh, int bs, int tid, int nthr) {
-  const int nitems = (P.L / R) * nb;
-  const int step = P.L / P.n[s];
+  const int nitems = P.m[s] * P.step[s] * nb;
+  const int step = P.step[s];
   const bool has_tw = P.m[s] > 1;
   for (int item = tid; item < nitems; item += nthr) {
     const BfAddr a = bf_decode(P, s, mode, item, wsh, bs);
@@ -342,7 +359,7 @@ PS_HD void gen_compute(GenAcc& g, const cplx* data, const cplx* tlo, const cplx*
                        const FftProg& P, int s, int mode, int nb, int wsh, int bs,
                        int group0, int lane) {
   const int r = P.radix[s];
-  const int nbutter = (P.L / r) * nb;
+  const int nbutter = P.m[s] * P.step[s] * nb;
   const int G = r < 64 ? 64 / r : 1;
   const int kpl = (r + 63) / 64;
   int sub = 0, k0 = lane;
@@ -357,8 +374,8 @@ PS_HD void gen_compute(GenAcc& g, const cplx* data, const cplx* tlo, const cplx*
   const BfAddr a = bf_decode(P, s, mode, bid, wsh, bs);
   g.addr0 = a.addr0;
   g.qstride = a.qstride;
-  const int step = P.L / P.n[s];
-  const int rstep = P.L / r;
+  const int step = P.step[s];
+  const int rstep = P.m[s] * P.step[s];
   int idx[PS_GEN_KPL];
   for (int u = 0; u < kpl; ++u) {
     g.acc[u] = make_double2(0.0, 0.0);
@@ -400,7 +417,7 @@ template <int DIR>
 PS_HD void run_stage_generic(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P,
                              int s, int mode, int nb, int wsh, int bs, int tid, int nthr) {
   const int r = P.radix[s];
-  const int nbutter = (P.L / r) * nb;
+  const int nbutter = P.m[s] * P.step[s] * nb;
   const int G = r < 64 ? 64 / r : 1;
   const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
   for (int g0 = wave * G; g0 < nbutter; g0 += nwaves * G) {
@@ -428,7 +445,7 @@ PS_HD void run_stage(cplx* data, const cplx* tlo, const cplx* thi, const FftProg
 // row-mode physical position of logical index i
 PS_HD int row_phys(const FftProg& P, int i) {
   if (P.Lb == 1) return i;
-  const int hi = i / P.Lb;
+  const int hi = ps_div(i, P.mg_Lb);
   return hi * P.Lbp + (i - hi * P.Lb);
 }
 // LDS elements one row-mode transform occupies

@@ -10,8 +10,15 @@
 // into two sub-passes (P = L1 * L2) that each stream the spectrum once.
 // Every pass stages its tile in LDS and runs the FftProg of fft_core.h there;
 // HBM is touched with >= 64 B (normally 256-512 B) contiguous segments only.
+//
+// Latency structure: global loads are issued in unrolled batches of PS_UNROLL per
+// thread before any of them is consumed, so a tile costs ~one HBM round trip, not one
+// per loop iteration; index tables and the 4-step twiddles of the tile are staged in
+// LDS once per workgroup.
 #pragma once
 #include "fft_core.h"
+
+#define PS_UNROLL 4
 
 // ---------------------------------------------------------------- arguments
 struct SrcMap {  // torus index i -> source index, or -1 (zero)
@@ -126,6 +133,7 @@ __global__ void k_row_fwd(RowFwdArgs a) {
   const double* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   cplx* dst = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
   const int pair0 = blockIdx.x * a.rp;
+  const int nthr = blockDim.x;
   // any non-zero source row in this block?
   bool any = false;
   for (int b = 0; b < a.rp; ++b) {
@@ -137,7 +145,7 @@ __global__ void k_row_fwd(RowFwdArgs a) {
     const cplx z = make_double2(0.0, 0.0);
     for (int b = 0; b < a.rp; ++b) {
       const int ra = 2 * (pair0 + b), rb = ra + 1;
-      for (int k = threadIdx.x; k < a.H; k += blockDim.x) {
+      for (int k = threadIdx.x; k < a.H; k += nthr) {
         if (ra < a.P) dst[(int64_t)ra * a.ld + k] = z;
         if (rb < a.P) dst[(int64_t)rb * a.ld + k] = z;
       }
@@ -151,14 +159,26 @@ __global__ void k_row_fwd(RowFwdArgs a) {
     const int sb = rb < a.P ? src_map(a.rmap, rb) : -1;
     const double* pa = src + (int64_t)sa * a.src_ld;
     const double* pb = src + (int64_t)sb * a.src_ld;
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-      const int sc = src_map(a.cmap, i);
-      double va = 0.0, vb = 0.0;
-      if (sc >= 0) {
-        if (sa >= 0) va = pa[sc];
-        if (sb >= 0) vb = pb[sc];
+    for (int i0 = threadIdx.x; i0 < L; i0 += nthr * PS_UNROLL) {
+      double va[PS_UNROLL], vb[PS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) {
+        const int i = i0 + u * nthr;
+        va[u] = 0.0;
+        vb[u] = 0.0;
+        if (i < L) {
+          const int sc = src_map(a.cmap, i);
+          if (sc >= 0) {
+            if (sa >= 0) va[u] = pa[sc];
+            if (sb >= 0) vb[u] = pb[sc];
+          }
+        }
       }
-      data[b * pitch + row_phys(P, i)] = make_double2(va, vb);
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) {
+        const int i = i0 + u * nthr;
+        if (i < L) data[b * pitch + row_phys(P, i)] = make_double2(va[u], vb[u]);
+      }
     }
   }
   __syncthreads();
@@ -167,13 +187,30 @@ __global__ void k_row_fwd(RowFwdArgs a) {
     const int ra = 2 * (pair0 + b), rb = ra + 1;
     if (ra >= a.P) break;
     const cplx* d = data + b * pitch;
-    for (int k = threadIdx.x; k < a.H; k += blockDim.x) {
-      const cplx zk = d[P.pos_phys[k]];
-      const cplx zm = d[P.pos_phys[k ? L - k : 0]];
-      const cplx A = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-      const cplx B = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
-      dst[(int64_t)ra * a.ld + k] = A;
-      if (rb < a.P) dst[(int64_t)rb * a.ld + k] = B;
+    for (int k0 = threadIdx.x; k0 < a.H; k0 += nthr * PS_UNROLL) {
+      unsigned pk[PS_UNROLL], pm[PS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) {
+        const int k = k0 + u * nthr;
+        pk[u] = 0;
+        pm[u] = 0;
+        if (k < a.H) {
+          pk[u] = P.pos_phys[k];
+          pm[u] = P.pos_phys[k ? L - k : 0];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) {
+        const int k = k0 + u * nthr;
+        if (k < a.H) {
+          const cplx zk = d[pk[u]];
+          const cplx zm = d[pm[u]];
+          const cplx A = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+          const cplx B = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+          dst[(int64_t)ra * a.ld + k] = A;
+          if (rb < a.P) dst[(int64_t)rb * a.ld + k] = B;
+        }
+      }
     }
   }
 }
@@ -188,45 +225,147 @@ __global__ void k_col(ColArgs a) {
   cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
   cplx* tlo = data + ((size_t)L << a.wsh);
   cplx* thi = tlo + P.n_lo;
+  cplx* stw = thi + P.n_hi;                          // [L] 4-step twiddle of tile row
+  int* spos = reinterpret_cast<int*>(stw + L);       // [L] digit-reversed LDS row
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
   const int tile = blockIdx.x % ntiles;
   const int o = blockIdx.x / ntiles;
   const int c0 = tile << a.wsh;
+  const int nthr = blockDim.x;
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   const cplx* src2 = a.src2 ? a.src2 + (int64_t)blockIdx.y * a.src2_bstride : nullptr;
   cplx* prod = a.prod_dst ? a.prod_dst + (int64_t)blockIdx.y * a.prod_bstride : nullptr;
   cplx* dst = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
+  const bool tw_on = a.tw_mode != 0 && o != 0;
   load_tw(tlo, thi, P);
+  for (int r = threadIdx.x; r < L; r += nthr) {
+    spos[r] = (int)P.pos[r];
+    if (tw_on) stw[r] = tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, o * r);
+  }
+  __syncthreads();
   const int tot = L << a.wsh;
   const int in_base = o * a.in_base_mul, out_base = o * a.out_base_mul;
-  for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
-    const int row = idx >> a.wsh, c = idx & (W - 1);
-    const int col = c0 + c;
-    cplx v = make_double2(0.0, 0.0);
-    if (col < a.ncols) {
-      const int64_t g = (int64_t)(in_base + row * a.in_stride) * a.ld + col;
-      v = src[g];
-      if (src2) {
-        v = cmul(v, src2[g]);
-        if (prod) prod[g] = v;
+  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+    cplx v[PS_UNROLL], v2[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
+      v[u] = make_double2(0.0, 0.0);
+      v2[u] = make_double2(1.0, 0.0);
+      if (idx < tot && col < a.ncols) {
+        const int64_t g = (int64_t)(in_base + row * a.in_stride) * a.ld + col;
+        v[u] = src[g];
+        if (src2) v2[u] = src2[g];
       }
-      if (a.tw_mode == 2 && o != 0 && row != 0)
-        v = cmulc(v, tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, o * row));
     }
-    const int lrow = DIR == PS_INV ? (int)P.pos[row] : row;
-    data[(lrow << a.wsh) + c] = v;
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      if (idx >= tot) continue;
+      const int row = idx >> a.wsh, c = idx & (W - 1);
+      cplx x = v[u];
+      if (src2) {
+        x = cmul(x, v2[u]);
+        if (prod && c0 + c < a.ncols) prod[(int64_t)(in_base + row * a.in_stride) * a.ld + c0 + c] = x;
+      }
+      if (a.tw_mode == 2 && tw_on) x = cmulc(x, stw[row]);
+      const int lrow = DIR == PS_INV ? spos[row] : row;
+      data[(lrow << a.wsh) + c] = x;
+    }
   }
   __syncthreads();
   lds_fft<DIR, GEN>(data, tlo, thi, P, PS_MODE_COL, W, a.wsh, 0);
-  for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < tot; idx += nthr) {
     const int row = idx >> a.wsh, c = idx & (W - 1);
     const int col = c0 + c;
     if (col >= a.ncols) continue;
-    const int lrow = DIR == PS_FWD ? (int)P.pos[row] : row;
-    cplx v = data[(lrow << a.wsh) + c];
-    if (a.tw_mode == 1 && o != 0 && row != 0)
-      v = cmul(v, tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, o * row));
-    dst[(int64_t)(out_base + row * a.out_stride) * a.ld + col] = v;
+    const int lrow = DIR == PS_FWD ? spos[row] : row;
+    cplx x = data[(lrow << a.wsh) + c];
+    if (a.tw_mode == 1 && tw_on) x = cmul(x, stw[row]);
+    dst[(int64_t)(out_base + row * a.out_stride) * a.ld + col] = x;
+  }
+}
+
+// ------------------------------------------------- fused convolution column pass
+// The last forward sub-pass of the day kernel, the spectral product with the state
+// (CalcSol.py:66) and the first inverse sub-pass work on the SAME tile (fixed outer
+// index o = k1, columns c0..c0+W): forward FFT over r2 leaves B_hat[k1 + L1 k2] at LDS
+// row pos[k2], which is exactly where the inverse program wants its input.  So B_hat
+// never goes to HBM:  load kernel tile -> FFT -> x *= A_hat (store new A_hat) -> iFFT ->
+// store.  Rows: kernel/out rows o*L2 + i, state rows o + L1*k.  Single-pass columns are
+// the case L1 = 1.
+struct ColFusedArgs {
+  const cplx* src;   // kernel after row pass (+ first column sub-pass when split)
+  cplx* state;       // A_hat, read; overwritten with the product when store_prod
+  cplx* dst;
+  int64_t src_bstride;
+  int ld, ncols, wsh, L1, L2, store_prod;
+  FftProg prog;      // length L2
+};
+
+template <bool GEN>
+__global__ void k_col_fused(ColFusedArgs a) {
+  const FftProg& P = a.prog;
+  const int L = P.L;
+  const int W = 1 << a.wsh;
+  cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
+  cplx* tlo = data + ((size_t)L << a.wsh);
+  cplx* thi = tlo + P.n_lo;
+  int* spos = reinterpret_cast<int*>(thi + P.n_hi);
+  const int ntiles = (a.ncols + W - 1) >> a.wsh;
+  const int tile = blockIdx.x % ntiles;
+  const int o = blockIdx.x / ntiles;
+  const int c0 = tile << a.wsh;
+  const int nthr = blockDim.x;
+  const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
+  load_tw(tlo, thi, P);
+  for (int r = threadIdx.x; r < L; r += nthr) spos[r] = (int)P.pos[r];
+  const int tot = L << a.wsh;
+  const int64_t base = (int64_t)o * a.L2;
+  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+    cplx v[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
+      v[u] = make_double2(0.0, 0.0);
+      if (idx < tot && col < a.ncols) v[u] = src[(base + row) * a.ld + col];
+    }
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      if (idx < tot) data[idx] = v[u];
+    }
+  }
+  __syncthreads();
+  lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, W, a.wsh, 0);
+  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+    cplx v[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      const int k = idx >> a.wsh, col = c0 + (idx & (W - 1));
+      v[u] = make_double2(0.0, 0.0);
+      if (idx < tot && col < a.ncols) v[u] = a.state[((int64_t)o + (int64_t)a.L1 * k) * a.ld + col];
+    }
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      if (idx >= tot) continue;
+      const int k = idx >> a.wsh, c = idx & (W - 1);
+      const int l = (spos[k] << a.wsh) + c;
+      const cplx x = cmul(v[u], data[l]);
+      data[l] = x;
+      if (a.store_prod && c0 + c < a.ncols)
+        a.state[((int64_t)o + (int64_t)a.L1 * k) * a.ld + c0 + c] = x;
+    }
+  }
+  __syncthreads();
+  lds_fft<PS_INV, GEN>(data, tlo, thi, P, PS_MODE_COL, W, a.wsh, 0);
+  for (int idx = threadIdx.x; idx < tot; idx += nthr) {
+    const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
+    if (col < a.ncols) a.dst[(base + row) * a.ld + col] = data[idx];
   }
 }
 
@@ -243,22 +382,41 @@ __global__ void k_row_inv(RowInvArgs a) {
   cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
   cplx* tlo = data + (size_t)a.rp * pitch;
   cplx* thi = tlo + P.n_lo;
-  double* red = reinterpret_cast<double*>(thi + P.n_hi);  // 3 * (blockDim/64) doubles
+  double* red = reinterpret_cast<double*>(thi + P.n_hi);  // 4 * (blockDim/64) doubles
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   const int pair0 = blockIdx.x * a.rp;
+  const int nthr = blockDim.x;
   load_tw(tlo, thi, P);
   for (int b = 0; b < a.rp; ++b) {
     const int ra = 2 * (pair0 + b), rb = ra + 1;
     const bool hasa = ra < a.P, hasb = rb < a.P;
     const cplx* pa = src + (int64_t)ra * a.ld;
     const cplx* pb = src + (int64_t)rb * a.ld;
-    for (int k = threadIdx.x; k < L; k += blockDim.x) {
-      const int kk = k < a.H ? k : L - k;
-      cplx A = make_double2(0.0, 0.0), B = A;
-      if (hasa) A = pa[kk];
-      if (hasb) B = pb[kk];
-      cplx z = k < a.H ? make_double2(A.x - B.y, A.y + B.x) : make_double2(A.x + B.y, B.x - A.y);
-      data[b * pitch + P.pos_phys[k]] = z;
+    for (int k0 = threadIdx.x; k0 < L; k0 += nthr * PS_UNROLL) {
+      cplx A[PS_UNROLL], B[PS_UNROLL];
+      unsigned pp[PS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) {
+        const int k = k0 + u * nthr;
+        A[u] = make_double2(0.0, 0.0);
+        B[u] = A[u];
+        pp[u] = 0;
+        if (k < L) {
+          const int kk = k < a.H ? k : L - k;
+          if (hasa) A[u] = pa[kk];
+          if (hasb) B[u] = pb[kk];
+          pp[u] = P.pos_phys[k];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) {
+        const int k = k0 + u * nthr;
+        if (k < L) {
+          const cplx z = k < a.H ? make_double2(A[u].x - B[u].y, A[u].y + B[u].x)
+                                 : make_double2(A[u].x + B[u].y, B[u].x - A[u].y);
+          data[b * pitch + pp[u]] = z;
+        }
+      }
     }
   }
   __syncthreads();
@@ -266,7 +424,7 @@ __global__ void k_row_inv(RowInvArgs a) {
   double* rec = a.rec + (int64_t)blockIdx.y * a.rec_bstride;
   double* rowsum = a.rowsum + (int64_t)blockIdx.y * a.stat_bstride;
   long long* rowcnt = a.rowcnt + (int64_t)blockIdx.y * a.stat_bstride;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthr >> 6;
   double pmax = 0.0;
   for (int b = 0; b < a.rp; ++b) {
     const int ra = 2 * (pair0 + b), rb = ra + 1;
@@ -274,7 +432,7 @@ __global__ void k_row_inv(RowInvArgs a) {
     const cplx* d = data + b * pitch;
     double sa = 0.0, sb = 0.0;
     int ca = 0, cb = 0;
-    for (int i = threadIdx.x; i < a.P; i += blockDim.x) {
+    for (int i = threadIdx.x; i < a.P; i += nthr) {
       const cplx z = d[row_phys(P, i)];
       const double va = z.x * a.scale, vb = z.y * a.scale;
       if (i < a.N) {
@@ -324,7 +482,18 @@ __global__ void k_row_inv(RowInvArgs a) {
       if (rb < a.N) { rowsum[rb] = tb; rowcnt[rb] = (long long)nbb; }
     }
   }
+  // one atomic per workgroup at most, and only when it can raise the maximum: every
+  // workgroup hitting the same word costs ~12 ns each, serialised
   for (int off = 32; off > 0; off >>= 1) pmax = fmax(pmax, __shfl_down(pmax, off));
-  if (lane == 0 && pmax > 0.0)
-    atomicMax(a.padmax + blockIdx.y, (unsigned long long)__double_as_longlong(pmax));
+  __syncthreads();
+  if (lane == 0) red[wave] = pmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int w = 0; w < nw; ++w) m = fmax(m, red[w]);
+    unsigned long long* pm = a.padmax + blockIdx.y;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m > 0.0 && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(pm, bits);
+  }
 }

@@ -103,6 +103,14 @@ inline bool ps_build_plan(int L, bool row_split, HostFftPlan* out) {
     P.La = L / P.Lb;
     P.Lbp = (P.Lb % 2 == 0) ? P.Lb + 1 : P.Lb;
   }
+  for (int s = 0; s < P.ns; ++s) {
+    P.step[s] = L / P.n[s];
+    P.mg_m[s] = ps_magic((uint32_t)P.m[s]);
+    P.mg_mh[s] = ps_magic((uint32_t)std::max(1, P.m[s] / P.Lb));
+    P.mg_nbf[s] = ps_magic((uint32_t)(L / P.radix[s]));
+  }
+  P.mg_Lb = ps_magic((uint32_t)P.Lb);
+  P.mg_La = ps_magic((uint32_t)P.La);
   // twiddles: w_L^t = exp(-2 pi i t / L) (forward sign), two-level tables
   P.tw_shift = (L <= 4096) ? 6 : 7;
   const int B = 1 << P.tw_shift;

@@ -143,7 +143,8 @@ static int set_lds_attr() {
   const void* ks[] = {(const void*)k_row_fwd<false>, (const void*)k_row_fwd<true>,
                       (const void*)k_row_inv<false>, (const void*)k_row_inv<true>,
                       (const void*)k_col<PS_FWD, false>, (const void*)k_col<PS_FWD, true>,
-                      (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>};
+                      (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>,
+                      (const void*)k_col_fused<false>, (const void*)k_col_fused<true>};
   for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   done = true;
   return PS_OK;
@@ -192,10 +193,10 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   const int W = 1 << a.wsh;
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)(ntiles * cp.n_outer), batch);
-  size_t lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
+  size_t lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.L) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
   while (lds > (size_t)kMaxLds && a.wsh > 0) {
     --a.wsh;
-    lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
+    lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.L) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
   }
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", lds);
   {
@@ -266,6 +267,51 @@ static int inv2d(ps_solver* s, const cplx* A, const cplx* B, cplx* prod, double*
     PS_TRY(launch_row_inv(s, s->T2.p, rec, stat_slot, 1, negval, stat_scale));
   }
   return PS_OK;
+}
+
+// forward transform of day kernels up to (not including) the last column sub-pass: that
+// one is fused with the spectral product and the first inverse sub-pass (k_col_fused)
+static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
+                         SrcMap rmap, SrcMap cmap, cplx* out, int batch) {
+  if (!s->split) return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr);
+  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, nullptr));
+  return launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, nullptr);
+}
+
+static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst) {
+  ColFusedArgs a;
+  DevPlan* plan = s->split ? &s->col_plan2 : &s->col_plan1;
+  a.src = kt; a.state = state; a.dst = dst;
+  a.src_bstride = 0;
+  a.ld = s->ld; a.ncols = s->H;
+  a.L1 = s->split ? s->L1 : 1;
+  a.L2 = s->split ? s->L2 : s->Pf;
+  a.store_prod = store_prod;
+  a.prog = plan->prog;
+  a.wsh = col_wsh(a.prog.L);
+  auto need = [&](int wsh) {
+    return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+  };
+  while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 0) --a.wsh;
+  if (need(a.wsh) > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", need(a.wsh));
+  const int W = 1 << a.wsh;
+  dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
+  ProfScope prof(s, PS_PROF_COL_INV_A);
+  if (plan->generic)
+    hipLaunchKernelGGL(k_col_fused<true>, grid, dim3(256), need(a.wsh), s->stream, a);
+  else
+    hipLaunchKernelGGL(k_col_fused<false>, grid, dim3(256), need(a.wsh), s->stream, a);
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
+// one day step: state_hat <- state_hat * K_hat (stored when store_prod), rec <- ifft2(...)
+static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, double* rec,
+                    int stat_slot, double negval, double stat_scale) {
+  PS_TRY(launch_col_fused(s, kt, state, store_prod, s->T1.p));
+  if (!s->split) return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
+  PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
+  return launch_row_inv(s, s->T2.p, rec, stat_slot, 1, negval, stat_scale);
 }
 
 static SrcMap map_plain(int n, int P) { return SrcMap{n, 0, P, 0}; }
@@ -491,7 +537,7 @@ static int transform_kernels(ps_solver* s, int first, int count) {
     PS_TRY(scatter_from_device(s, s->krow.p + o, s->kcol.p + o, s->kval.p + o, n,
                                s->kdense.p + (size_t)d * K * K, K, off));
   }
-  PS_TRY(fwd2d(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count, nullptr));
+  PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count));
   s->bhat_first = first;
   s->bhat_count = count;
   return PS_OK;
@@ -568,7 +614,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     for (int d = c0; d < c0 + cn; ++d) {
       const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
       double* rec = s->recs[PS_REC_CHAIN][d];
-      PS_TRY(inv2d(s, s->Ahat.p, B, s->Ahat.p, rec, d, negval, stat_scale));
+      PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale));
       PS_TRY(finalize_day(s, d, renorm));
       PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
     }
@@ -655,9 +701,9 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
     PS_TRY(ensure_record(s, PS_REC_BACK, i));
     PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)K * K * sizeof(double), s->stream));
     PS_TRY(scatter_from_device(s, s->orow.p, s->ocol.p, s->oval.p, n, s->kdense.p, K, 0));
-    PS_TRY(fwd2d(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, 1, nullptr));
+    PS_TRY(fwd2d_partial(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, 1));
     double* rec = s->recs[PS_REC_BACK][i];
-    PS_TRY(inv2d(s, s->Chat.p, s->Bhat.p, s->Chat.p, rec, i, negval, stat_scale));
+    PS_TRY(conv_inv(s, s->Bhat.p, s->Chat.p, 1, rec, i, negval, stat_scale));
     PS_TRY(finalize_day(s, i, 0));
     PS_TRY(refft_if_flag(s, rec, s->Chat.p, i));  // cuda_lib.py:208-214 semantics
   }
