@@ -23,10 +23,14 @@ struct DayStats {
   int pad_;
 };
 
-// one block: reduce per-row statistics of one day in a fixed order
-static __global__ void k_day_finalize(const double* rowsum, const long long* rowcnt,
-                               const unsigned long long* padmax, int N, int renorm,
-                               DayStats* out, int* flag_out) {
+// one block per day: reduce the per-row statistics in a fixed order
+static __global__ void k_day_finalize(const double* rowsum_, const long long* rowcnt_,
+                               const unsigned long long* padmax_, int N, int renorm,
+                               DayStats* out_) {
+  const double* rowsum = rowsum_ + (int64_t)blockIdx.x * N;
+  const long long* rowcnt = rowcnt_ + (int64_t)blockIdx.x * N;
+  const unsigned long long* padmax = padmax_ + blockIdx.x;
+  DayStats* out = out_ + blockIdx.x;
   __shared__ double ssum[256];
   __shared__ long long scnt[256];
   double s = 0.0;
@@ -54,7 +58,6 @@ static __global__ void k_day_finalize(const double* rowsum, const long long* row
     d.flag = d.padmax > 1e-8 ? 1 : 0;
     d.pad_ = 0;
     *out = d;
-    if (flag_out) *flag_out = d.flag;
   }
 }
 

@@ -24,6 +24,12 @@
 struct SrcMap {  // torus index i -> source index, or -1 (zero)
   int n1, off1, lo2, off2;
 };
+// Flag-conditional passes (CalcSol.py:200-201) read the day's pad maximum (bit pattern of
+// a non-negative double, written by the inverse row pass) and return at once unless it
+// exceeds 1e-8 -- the boundary flag never travels to the host.
+__device__ __forceinline__ bool pred_skip(const unsigned long long* pred) {
+  return pred && !(__longlong_as_double((long long)*pred) > 1e-8);
+}
 __device__ __forceinline__ int src_map(const SrcMap& m, int i) {
   if (i < m.n1) return i + m.off1;
   if (i >= m.lo2) return i - m.lo2 + m.off2;
@@ -39,7 +45,8 @@ struct RowFwdArgs {
   int64_t dst_bstride;
   int H, ld, P;  // dst is [P][ld], H valid columns
   int rp;        // row pairs per block
-  const int* pred;
+  int skip_zero;  // all-zero row pairs are not written (the next pass knows they are zero)
+  const unsigned long long* pred;
   FftProg prog;
 };
 
@@ -55,7 +62,8 @@ struct ColArgs {
   const cplx* tp_lo;
   const cplx* tp_hi;
   int tp_shift;
-  const int* pred;
+  int vr_n1, vr_lo2;  // input rows r with vr_n1 <= r < vr_lo2 are known zeros: not read
+  const unsigned long long* pred;
   FftProg prog;
 };
 
@@ -123,7 +131,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ps_lds_raw[];
 // B = (Z_k - conj Z_{L-k})/(2i).  Rows outside the source map are zero.
 template <bool GEN>
 __global__ void k_row_fwd(RowFwdArgs a) {
-  if (a.pred && *a.pred == 0) return;
+  if (pred_skip(a.pred)) return;
   const FftProg& P = a.prog;
   const int L = P.L;
   const int pitch = row_pitch(P);
@@ -142,6 +150,7 @@ __global__ void k_row_fwd(RowFwdArgs a) {
     if (rb < a.P && src_map(a.rmap, rb) >= 0) any = true;
   }
   if (!any) {
+    if (a.skip_zero) return;
     const cplx z = make_double2(0.0, 0.0);
     for (int b = 0; b < a.rp; ++b) {
       const int ra = 2 * (pair0 + b), rb = ra + 1;
@@ -218,7 +227,7 @@ __global__ void k_row_fwd(RowFwdArgs a) {
 // ---------------------------------------------------------------- columns
 template <int DIR, bool GEN>
 __global__ void k_col(ColArgs a) {
-  if (a.pred && *a.pred == 0) return;
+  if (pred_skip(a.pred)) return;
   const FftProg& P = a.prog;
   const int L = P.L;
   const int W = 1 << a.wsh;
@@ -253,8 +262,9 @@ __global__ void k_col(ColArgs a) {
       const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
       v[u] = make_double2(0.0, 0.0);
       v2[u] = make_double2(1.0, 0.0);
-      if (idx < tot && col < a.ncols) {
-        const int64_t g = (int64_t)(in_base + row * a.in_stride) * a.ld + col;
+      const int grow = in_base + row * a.in_stride;
+      if (idx < tot && col < a.ncols && (grow < a.vr_n1 || grow >= a.vr_lo2)) {
+        const int64_t g = (int64_t)grow * a.ld + col;
         v[u] = src[g];
         if (src2) v2[u] = src2[g];
       }
@@ -301,6 +311,7 @@ struct ColFusedArgs {
   cplx* dst;
   int64_t src_bstride;
   int ld, ncols, wsh, L1, L2, store_prod;
+  int vr_n1, vr_lo2;  // kernel rows r with vr_n1 <= r < vr_lo2 are known zeros: not read
   FftProg prog;      // length L2
 };
 
@@ -330,7 +341,8 @@ __global__ void k_col_fused(ColFusedArgs a) {
       const int idx = idx0 + u * nthr;
       const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
       v[u] = make_double2(0.0, 0.0);
-      if (idx < tot && col < a.ncols) v[u] = src[(base + row) * a.ld + col];
+      if (idx < tot && col < a.ncols && (base + row < a.vr_n1 || base + row >= a.vr_lo2))
+        v[u] = src[(base + row) * a.ld + col];
     }
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {

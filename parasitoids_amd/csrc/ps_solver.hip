@@ -78,8 +78,9 @@ struct ps_solver {
   DevBuf<long long> rowoff;    // [N]
   DevBuf<unsigned long long> padmax;
   DevBuf<DayStats> dstats;
-  DevBuf<int> flags;
   int nstat = 0;
+  int last_renorm = 0;
+  int kt_vr_n1 = 0x7fffffff, kt_vr_lo2 = 0x7fffffff;  // zero-row window of the kernel transforms
   // staging for fetch / uploads
   DevBuf<int> orow, ocol;
   DevBuf<double> oval;
@@ -151,7 +152,8 @@ static int set_lds_attr() {
 }
 
 static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
-                          SrcMap rmap, SrcMap cmap, cplx* dst, int batch, const int* pred) {
+                          SrcMap rmap, SrcMap cmap, cplx* dst, int batch,
+                          const unsigned long long* pred, int skip_zero = 0) {
   RowFwdArgs a;
   a.src = src; a.src_bstride = src_bstride; a.src_ld = src_ld;
   a.rmap = rmap; a.cmap = cmap;
@@ -160,6 +162,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   a.prog = s->row_plan.prog;
   a.rp = row_pairs(a.prog);
   a.pred = pred;
+  a.skip_zero = skip_zero;
   const int npairs = (s->Pf + 1) / 2;
   dim3 grid((npairs + a.rp - 1) / a.rp, batch);
   const int thr = row_threads(a.prog.L);
@@ -176,7 +179,8 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
 
 template <int DIR>
 static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cplx* src2,
-                      cplx* prod, cplx* dst, int batch, int64_t src2_bstride, const int* pred) {
+                      cplx* prod, cplx* dst, int batch, int64_t src2_bstride,
+                      const unsigned long long* pred, int vr_n1 = 0x7fffffff, int vr_lo2 = 0x7fffffff) {
   ColArgs a;
   a.src = src; a.src2 = src2; a.prod_dst = prod; a.dst = dst;
   const int64_t bs = (int64_t)s->Pf * s->ld;
@@ -190,6 +194,7 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   a.tw_mode = cp.tw_mode;
   a.tp_lo = s->tp_lo.p; a.tp_hi = s->tp_hi.p; a.tp_shift = s->tp_shift;
   a.pred = pred;
+  a.vr_n1 = vr_n1; a.vr_lo2 = vr_lo2;
   const int W = 1 << a.wsh;
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)(ntiles * cp.n_outer), batch);
@@ -244,12 +249,13 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
 
 // forward 2-D transform of `batch` real sources into `out`
 static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_ld, SrcMap rmap,
-                 SrcMap cmap, cplx* out, int batch, const int* pred) {
-  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred));
+                 SrcMap cmap, cplx* out, int batch, const unsigned long long* pred) {
+  // zero source rows are neither written by the row pass nor read by the first column pass
+  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred, 1));
   if (s->fwd_passes.size() == 1) {
-    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred, rmap.n1, rmap.lo2));
   } else {
-    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred, rmap.n1, rmap.lo2));
     PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[1], s->T2.p, nullptr, nullptr, out, batch, 0, pred));
   }
   return PS_OK;
@@ -273,9 +279,14 @@ static int inv2d(ps_solver* s, const cplx* A, const cplx* B, cplx* prod, double*
 // one is fused with the spectral product and the first inverse sub-pass (k_col_fused)
 static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
                          SrcMap rmap, SrcMap cmap, cplx* out, int batch) {
-  if (!s->split) return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr);
-  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, nullptr));
-  return launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, nullptr);
+  s->kt_vr_n1 = s->kt_vr_lo2 = 0x7fffffff;
+  if (!s->split) {
+    s->kt_vr_n1 = rmap.n1;  // the fused pass reads the row-pass output directly
+    s->kt_vr_lo2 = rmap.lo2;
+    return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr, 1);
+  }
+  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, nullptr, 1));
+  return launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, nullptr, rmap.n1, rmap.lo2);
 }
 
 static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst) {
@@ -287,6 +298,7 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   a.L1 = s->split ? s->L1 : 1;
   a.L2 = s->split ? s->L2 : s->Pf;
   a.store_prod = store_prod;
+  a.vr_n1 = s->kt_vr_n1; a.vr_lo2 = s->kt_vr_lo2;
   a.prog = plan->prog;
   a.wsh = col_wsh(a.prog.L);
   auto need = [&](int wsh) {
@@ -336,15 +348,16 @@ static int ensure_stats(ps_solver* s, int n) {
   PS_TRY(s->rowcnt.ensure((size_t)(n + 1) * s->N));
   PS_TRY(s->padmax.ensure(n + 1));
   PS_TRY(s->dstats.ensure(n + 1));
-  PS_TRY(s->flags.ensure(n + 1));
   s->nstat = n;
   return PS_OK;
 }
 
-static int finalize_day(ps_solver* s, int slot, int renorm) {
-  hipLaunchKernelGGL(k_day_finalize, dim3(1), dim3(256), 0, s->stream,
+// reduce the per-row statistics of `count` consecutive day slots (one block each)
+static int finalize_days(ps_solver* s, int slot, int count, int renorm) {
+  if (count <= 0) return PS_OK;
+  hipLaunchKernelGGL(k_day_finalize, dim3(count), dim3(256), 0, s->stream,
                      s->rowsum.p + (int64_t)slot * s->N, s->rowcnt.p + (int64_t)slot * s->N,
-                     s->padmax.p + slot, s->N, renorm, s->dstats.p + slot, s->flags.p + slot);
+                     s->padmax.p + slot, s->N, renorm, s->dstats.p + slot);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
@@ -352,7 +365,7 @@ static int finalize_day(ps_solver* s, int slot, int renorm) {
 // truncate to the domain and re-transform when the day's flag is set (CalcSol.py:200-201)
 static int refft_if_flag(ps_solver* s, const double* rec, cplx* hat, int slot) {
   return fwd2d(s, rec, 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), hat, 1,
-               s->flags.p + slot);
+               s->padmax.p + slot);
 }
 
 // ------------------------------------------------------------------- create
@@ -440,7 +453,7 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
     for (double* p : v)
       if (p) (void)hipFree(p);
   s->rowsum.release(); s->rowcnt.release(); s->rowoff.release(); s->padmax.release();
-  s->dstats.release(); s->flags.release();
+  s->dstats.release();
   s->orow.release(); s->ocol.release(); s->oval.release(); s->wptr.release(); s->wval.release();
   for (auto& r : s->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : s->prof_pool) (void)hipEventDestroy(e);
@@ -608,6 +621,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   PS_TRY(ensure_stats(s, std::max(4, first + count)));
   for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
   PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
+  s->last_renorm = renorm;
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
     PS_TRY(transform_kernels(s, c0, cn));
@@ -615,7 +629,6 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
       double* rec = s->recs[PS_REC_CHAIN][d];
       PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale));
-      PS_TRY(finalize_day(s, d, renorm));
       PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
     }
   }
@@ -625,6 +638,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
 extern "C" int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out) {
   if (!s || !out || first < 0 || count < 0 || first + count > s->nstat) return ps_fail(PS_ERR_BAD_ARG, "chain_stats: bad range");
   PS_HIP(hipSetDevice(s->device));
+  PS_TRY(finalize_days(s, first, count, s->last_renorm));
   PS_HIP(hipStreamSynchronize(s->stream));
   static_assert(sizeof(ps_day_stats) == sizeof(DayStats), "stats layout");
   PS_HIP(hipMemcpy(out, s->dstats.p + first, (size_t)count * sizeof(DayStats), hipMemcpyDeviceToHost));
@@ -669,7 +683,7 @@ extern "C" int ps_solver_get_cursol(ps_solver* s, double negval, double stat_sca
   PS_HIP(hipMemsetAsync(s->padmax.p, 0, sizeof(unsigned long long), s->stream));
   double* rec = s->recs[PS_REC_CHAIN][0];
   PS_TRY(inv2d(s, s->Ahat.p, nullptr, nullptr, rec, 0, negval, stat_scale));
-  PS_TRY(finalize_day(s, 0, renorm));
+  s->last_renorm = renorm;
   PS_TRY(refft_if_flag(s, rec, s->Ahat.p, 0));
   if (stats) PS_TRY(ps_chain_stats(s, 0, 1, stats));
   return PS_OK;
@@ -704,9 +718,9 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
     PS_TRY(fwd2d_partial(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, 1));
     double* rec = s->recs[PS_REC_BACK][i];
     PS_TRY(conv_inv(s, s->Bhat.p, s->Chat.p, 1, rec, i, negval, stat_scale));
-    PS_TRY(finalize_day(s, i, 0));
     PS_TRY(refft_if_flag(s, rec, s->Chat.p, i));  // cuda_lib.py:208-214 semantics
   }
+  s->last_renorm = 0;
   if (stats && nfilt > 0) PS_TRY(ps_chain_stats(s, 0, nfilt, stats));
   return PS_OK;
 }
@@ -733,7 +747,7 @@ extern "C" int ps_record_stats(ps_solver* s, int kind, int idx, double negval, d
   PS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_day_finalize, dim3(1), dim3(256), 0, s->stream, s->rowsum.p + (int64_t)slot * s->N,
                      s->rowcnt.p + (int64_t)slot * s->N, s->padmax.p + slot, s->N, renorm,
-                     s->dstats.p + slot, (int*)nullptr);
+                     s->dstats.p + slot);
   PS_HIP(hipGetLastError());
   PS_HIP(hipStreamSynchronize(s->stream));
   PS_HIP(hipMemcpy(out, s->dstats.p + slot, sizeof(DayStats), hipMemcpyDeviceToHost));
