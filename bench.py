@@ -27,13 +27,35 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # split of SURVEY 8d's W_day = 96 P^2 over this implementation's kernels
 ALG_P2 = {
     'row_fwd': 16.0,     # kernel R2C row pass: 8 in + 8 out
-    'col_fwd_a': 8.0,    # forward column pass (16 P^2) split over two sub-pass launches
-    'col_fwd_b': 8.0,
-    'col_inv_a': 32.0,   # spectral product (24) + first half of the inverse column pass (8)
-    'col_inv_b': 8.0,
+    'col_fwd_a': 8.0,    # first half of the kernel's forward column pass (16 P^2 in two sub-passes)
+    'col_fwd_b': 8.0,    # second half -- only the state FFT uses it unfused
+    'col_inv_a': 40.0,   # fused: kernel column sub-pass 2 (8) + spectral product (24) + inverse sub-pass 1 (8)
+    'col_inv_b': 8.0,    # inverse column sub-pass 2
     'row_inv': 24.0,     # inverse C2R row pass (16) + epilogue read of the real field (8)
     'refft_pred': 0.0,   # flag-conditional re-FFT launches (40 P^2 per flagged day; no-ops here)
 }
+# kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
+PMC_NAME = {'row_inv': 'void k_row_inv<false>', 'col_inv_a': 'void k_col_fused<false>',
+            'col_inv_b': 'void k_col<1, false>'}
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the latest committed rocprofv3 PMC
+    summary (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE);
+    None when no summary covers the kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_pmc.json')))
+    name = PMC_NAME.get(kernel_class)
+    if not files or name is None:
+        return None, None
+    best = None
+    for e in json.load(open(files[-1])):
+        if e['kernel'] == name and (best is None or e['dispatches'] > best['dispatches']):
+            best = e
+    if best is None:
+        return None, None
+    return (best['fetch_corrected_MB'] + best['write_size_MB']) * 1024 * 1024, os.path.basename(files[-1])
+
 
 
 def parse():
@@ -156,6 +178,7 @@ def main():
                            'alg_GBps': round(alg / (avg * 1e-3) / 1e9, 1)}
         dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['launches_per_step'])
         ach = kern[dom]['alg_GBps']
+        traffic, traffic_src = pmc_traffic(dom) if (R, K, nd) == (2048, 2049, 30) else (None, None)
         out = {
             'metric': 'grid-days/sec on 4096^2 fp64 domain',
             'value': round(value, 3),
@@ -172,7 +195,8 @@ def main():
             'alg_bytes_per_grid_day': 96.0 * P * P,
             'alg_GBps_whole_chain': round(value / world * 96.0 * P * P / 1e9, 1),
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None},
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'alg_bytes_per_launch': ALG_P2[dom] * P * P, 'traffic_source': traffic_src},
             'kernels': kern,
         }
         if world == 1 and not args.no_cpu_baseline:
