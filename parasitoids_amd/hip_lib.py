@@ -23,6 +23,22 @@ def _coo_arrays(A):
     return L.i32(A.row), L.i32(A.col), L.f64(A.data), A.shape
 
 
+def _create_solver(lib, handle, dev, dom_len, max_shape, mode):
+    """ps_solver_create with mode 'exact' | 'fast' | 'auto' (exact when the reference's pad
+    size can be planned -- every prime factor <= 1024 -- else the 7-smooth fast size).
+    Returns the mode actually used."""
+    if mode not in ('exact', 'fast', 'auto'):
+        raise ValueError("mode must be 'exact', 'fast' or 'auto'")
+    if mode != 'fast':
+        rc = lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, L.MODE_EXACT)
+        if rc == L.PS_OK:
+            return 'exact'
+        if mode == 'exact' or rc != L.PS_ERR_UNSUPPORTED:
+            L.check(rc)
+    L.check(lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, L.MODE_FAST))
+    return 'fast'
+
+
 class HipSolve():
     """Device-resident Fourier-space solution, cf. `cuda_lib.CudaSolve`."""
 
@@ -33,7 +49,8 @@ class HipSolve():
             A: First day's spread, sparse matrix (square, N x N)
             max_shape: Shape of the largest filter (cuda_lib.py:18-28)
             mode: 'exact' transforms on the reference's pad P = N + max_shape//2;
-                  'fast' on the next even 7-smooth size >= P'''
+                  'fast' on the next even 7-smooth size >= P; 'auto' = exact when P can be
+                  planned (prime factors <= 1024), else fast'''
         self._h = L._VP()
         self._lib = L.load()
         row, col, val, shape = _coo_arrays(A)
@@ -48,14 +65,42 @@ class HipSolve():
         mmid = ms // 2
         self.pad_shape = (int(shape[0] + mmid[0]), int(shape[1] + mmid[1]))
         dev = L.default_device() if device is None else device
-        L.check(self._lib.ps_solver_create(C.byref(self._h), dev, self.dom_len, int(ms[0]),
-                                           L.MODE_FAST if mode == 'fast' else L.MODE_EXACT))
+        self.mode = _create_solver(self._lib, self._h, dev, self.dom_len, int(ms[0]), mode)
         info = [C.c_int32() for _ in range(4)]
         L.check(self._lib.ps_solver_info(self._h, *[C.byref(v) for v in info]))
         self.fft_len = info[2].value
         L.check(self._lib.ps_solver_set_state_coo(self._h, L.p_i32(row), L.p_i32(col),
                                                   L.p_f64(val), len(val)))
         self._nk = 0
+
+    @classmethod
+    def from_model(cls, model, i, max_shape, mode='exact', device=None):
+        '''Solver whose first-day state is day i of `model`'s last device batch, re-centred
+        into the domain (Run.py:454-458) without leaving the GPU.'''
+        self = cls.__new__(cls)
+        self._h = L._VP()
+        self._lib = L.load()
+        ms = int(np.array(max_shape).ravel()[0])
+        N = 2 * int(model.last['args'][6]) + 1
+        self.dom_len = N
+        self.pad_shape = (N + ms // 2, N + ms // 2)
+        dev = L.default_device() if device is None else device
+        self.mode = _create_solver(self._lib, self._h, dev, N, ms, mode)
+        info = [C.c_int32() for _ in range(4)]
+        L.check(self._lib.ps_solver_info(self._h, *[C.byref(v) for v in info]))
+        self.fft_len = info[2].value
+        self._nk = 0
+        self.set_state_from_model(model, i)
+        return self
+
+    def set_state_from_model(self, model, i):
+        L.check(self._lib.ps_solver_set_state_from_model(self._h, model._h, int(i)))
+
+    def set_kernels_from_model(self, model, first, count):
+        '''Adopt days [first, first+count) of the model's last batch as the chain's day
+        kernels, device to device.'''
+        L.check(self._lib.ps_chain_set_kernels_from_model(self._h, model._h, int(first), int(count)))
+        self._nk = int(count)
 
     def set_state(self, A):
         '''Replace the Fourier-space solution by fft2(A) (what the constructor does,

@@ -1,0 +1,96 @@
+"""Device-resident evaluation of the population model for given parameters -- the
+compute body of the reference's `Bayes_Run.pop_model` (Bayes_Run.py:204-336): scatter the
+sampled parameters, build one probability-mass kernel per day (`prob_mass`), re-centre the
+release-day kernel, run `get_populations`.  Here the day kernels never leave the GPU: the
+model batch hands its COO pool straight to the solver.
+
+The PyMC sampler, the priors and the observation likelihood of Bayes_Run are not part of
+this package; "MCMC samples/hour" is measured as evaluations of this
+body per hour (bench_bayes.py).
+"""
+import numpy as np
+
+from . import _lib as L
+from . import ParasitoidModel as PM
+
+
+class PopModel():
+    def __init__(self, wind_data, days=None, domain_info=(10000.0, 400), r_number=130000,
+                 r_start=None, mode='auto', device=None, max_solvers=4):
+        '''wind_data: dict day -> [T,3] (PM.get_wind_data); r_dur = 1 releases (Kalbar,
+        Run.py:126-138).  mode: 'exact' | 'fast' | 'auto' (DESIGN.md section 5).'''
+        from . import hip_lib
+        self._hip = hip_lib
+        self.model = PM.WindModel(wind_data, device=device)
+        self.days = list(self.model.days if days is None else days)
+        self.rad_dist, self.rad_res = float(domain_info[0]), int(domain_info[1])
+        self.r_number = r_number
+        self.r_start = r_start
+        self.mode = mode
+        self.device = device
+        self._solvers = {}
+        self._max_solvers = max_solvers
+        self.solver = None
+        self.stats = None
+
+    def close(self):
+        for s in self._solvers.values():
+            s.close()
+        self._solvers = {}
+        self.model.close()
+
+    def _solver_for(self, max_shape):
+        key = int(max_shape)
+        s = self._solvers.pop(key, None)
+        if s is None:
+            if len(self._solvers) >= self._max_solvers:
+                self._solvers.pop(next(iter(self._solvers))).close()
+            s = self._hip.HipSolve.from_model(self.model, 0, [key, key], mode=self.mode,
+                                              device=self.device)
+        else:
+            s.set_state_from_model(self.model, 0)
+        self._solvers[key] = s          # most recently used last
+        return s
+
+    def evaluate(self, hparams, Dparams, Dlparams, mu_r, n_periods, ndays=None):
+        '''One model evaluation; results stay on the device.  Returns the per-day
+        statistics [(nnz, total population above 1e-8), ...], day 0 first.'''
+        nd = len(self.days) if ndays is None else ndays
+        starts = [self.r_start] + [None] * (nd - 1)
+        kshape, nnz, warned, status = self.model.build(
+            self.days[:nd], hparams, Dparams, Dlparams, mu_r, n_periods, self.rad_dist,
+            self.rad_res, starts)
+        for i in range(nd):
+            self.model.check(i)
+        solver = self._solver_for(int(kshape.max()))
+        self.solver = solver
+        scale = float(self.r_number)          # dist(1) = 1 for a one-day release
+        st0 = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
+        out = [(st0.nnz, st0.sum * scale)]
+        if nd > 1:
+            solver.set_kernels_from_model(self.model, 1, nd - 1)
+            solver.run_chain(0, nd - 1, negval=1e-8, scale=scale, renorm=False)
+            self.stats = solver.chain_stats(0, nd - 1)
+            out += [(s.nnz, s.sum) for s in self.stats]
+        return out
+
+    def population(self, day):
+        '''Day `day` (0 = release day) of the last evaluation as a csr matrix, the value
+        `get_populations` returns (CalcSol.py:236-237, :322-323).'''
+        solver = self.solver
+        scale = float(self.r_number)
+        if day == 0:
+            st = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
+            return solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, scale, st.nnz).tocsr()
+        st = self.stats[day - 1]
+        return solver._fetch(L.REC_CHAIN, day - 1, 1e-8, scale, 0.0, 1.0, st.nnz).tocsr()
+
+    def gather(self, day, rows, cols):
+        '''Population density at the given cells of one day (what popdensity_grid /
+        popdensity_to_emergence read from the daily solutions, Bayes_funcs.py:20-179).'''
+        solver = self.solver
+        scale = float(self.r_number)
+        kind, idx = (L.REC_STATE, 0) if day == 0 else (L.REC_CHAIN, day - 1)
+        dense = solver.dense(kind, idx)
+        v = dense[np.asarray(rows), np.asarray(cols)] * scale
+        return np.where(v < 1e-8, 0.0, v)

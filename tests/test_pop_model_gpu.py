@@ -1,0 +1,43 @@
+"""GPU parity of the device-resident population-model evaluation (the body of the
+reference's Bayes_Run.pop_model) against G7: get_populations on Kalbar, R=400, 18 days
+(reference settings, Bayes_Run.py:91; P = 1121 = 19*59, exact torus)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import HP, DP, DLP, MU_R, NPER, coo_from, assert_summary
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pop_model_kalbar_r400(golden, golden_dir):
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.pop_model import PopModel
+    g = golden('g7_populations')
+    wd, days = PM.get_wind_data(os.path.join(golden_dir, 'data', 'kalbar'), 30, '00:00')
+    pm = PopModel(wd, days, domain_info=(10000.0, 400), r_number=130000)
+    stats = pm.evaluate(HP, DP, DLP, MU_R, NPER)
+    assert len(stats) == 18
+    assert int(pm.model.last['kshape'].max()) == int(g['r400_max_shape'][0])
+    # the device-built day kernels equal the reference's
+    for i in (0, 7, 17):
+        ref = coo_from(g, 'r400_pmf%d' % i)
+        got = pm.model.fetch(i)
+        assert got.shape == ref.shape and got.nnz == ref.nnz
+        assert np.abs(got.data - ref.data).max() < 5e-15
+    pos = g['r400_pos']
+    for d in range(18):
+        pop = pm.population(d)
+        assert_summary(g, 'r400_sum%d' % d, pop, pos, rtol=1e-9, atol=1e-7, nnz_slack=6)
+        assert abs(stats[d][1] - float(g['r400_sum%d_sum' % d])) < 1e-6 * 130000
+    # second evaluation with other parameters reuses the context; first one is reproducible
+    s2 = pm.evaluate(HP, (150.0, 160.0, -0.1), DLP, 1.0, NPER)
+    assert s2[5][0] != stats[5][0]
+    s3 = pm.evaluate(HP, DP, DLP, MU_R, NPER)
+    assert [a[0] for a in s3] == [a[0] for a in stats]
+    assert max(abs(a[1] - b[1]) for a, b in zip(s3, stats)) == 0.0      # bitwise reproducible
+    v = pm.gather(3, [400, 390], [400, 410])
+    ref = pm.population(3)
+    assert abs(v[0] - ref[400, 400]) < 1e-9 and abs(v[1] - ref[390, 410]) < 1e-9
+    pm.close()
