@@ -24,6 +24,8 @@ struct BvuRule {
   double x[PM_MAX_NODES];    // abscissae
   double sn1[PM_MAX_NODES];  // sin(asr (x+1)/2)
   double sn2[PM_MAX_NODES];  // sin(asr (-x+1)/2)
+  double iv1[PM_MAX_NODES];  // 1 / (1 - sn1^2)
+  double iv2[PM_MAX_NODES];  // 1 / (1 - sn2^2)
   double asr;                // asin(r)
 };
 
@@ -63,10 +65,10 @@ __device__ __forceinline__ double pm_bvu(const BvuRule& R, double h, double k) {
   if (!R.high) {
     const double hs = (h * h + k * k) / 2;
     for (int i = 0; i < R.lg; ++i) {
-      double sn = R.sn1[i];
-      bvn = bvn + R.w[i] * exp((sn * hk - hs) / (1 - sn * sn));
-      sn = R.sn2[i];
-      bvn = bvn + R.w[i] * exp((sn * hk - hs) / (1 - sn * sn));
+      // (sn hk - hs)/(1 - sn^2) with the reciprocal precomputed on the host (<= 1 ulp
+      // difference in the exponent's argument)
+      bvn = bvn + R.w[i] * exp((R.sn1[i] * hk - hs) * R.iv1[i]);
+      bvn = bvn + R.w[i] * exp((R.sn2[i] * hk - hs) * R.iv2[i]);
     }
     return bvn * R.asr / (2 * TWOPI) + pm_phi(-h) * pm_phi(-k);
   }
@@ -104,6 +106,21 @@ __device__ __forceinline__ double pm_bvu(const BvuRule& R, double h, double k) {
   return bvn;
 }
 
+// pm_bvu with Phi(-h), Phi(-k) supplied (they are shared by a whole row / column of the
+// corner grid); identical arithmetic to pm_bvu
+__device__ __forceinline__ double pm_bvu_phi(const BvuRule& R, double h, double k, double ph, double pk) {
+  if (R.high) return pm_bvu(R, h, k);
+  const double TWOPI = 6.283185307179586;
+  const double hk = h * k;
+  const double hs = (h * h + k * k) / 2;
+  double bvn = 0.0;
+  for (int i = 0; i < R.lg; ++i) {
+    bvn = bvn + R.w[i] * exp((R.sn1[i] * hk - hs) * R.iv1[i]);
+    bvn = bvn + R.w[i] * exp((R.sn2[i] * hk - hs) * R.iv2[i]);
+  }
+  return bvn * R.asr / (2 * TWOPI) + ph * pk;
+}
+
 // rectangle probability of N(mu, S) on [xl,xu] x [yl,yu] as mvnun computes it
 __device__ __forceinline__ double pm_rect(const BvuRule& R, double sdx, double sdy, double mux,
                                           double muy, double xl, double xu, double yl, double yu) {
@@ -134,11 +151,12 @@ __device__ __forceinline__ int pm_support(const BvuRule& R, double sdx, double s
 // ParasitoidModel.py:282-309 with f_time_prob :243-267 and g_wind_prob :231-240.
 // One block per day; the two cumulative sums run sequentially like np.cumsum.
 __global__ void k_hprob(const double* __restrict__ wind, ModelParams mp, const int* day_idx,
-                        double* hprob /*[nd][T]*/, double* scratch /*[nd][3][T]*/) {
+                        double* hprob /*[nd][T]*/, double* scratch /*unused*/) {
+  extern __shared__ double hp_lds[];  // f[n], g[n], c2[n]
   const int d = blockIdx.x;
   const int n = mp.T;
   const double* w = wind + (int64_t)day_idx[d] * n * 3;
-  double* f = scratch + (int64_t)d * 3 * n;
+  double* f = hp_lds;
   double* g = f + n;
   double* c2 = g + n;
   double* h = hprob + (int64_t)d * n;
@@ -155,7 +173,7 @@ __global__ void k_hprob(const double* __restrict__ wind, ModelParams mp, const i
   __syncthreads();
   __shared__ double s_max;
   if (threadIdx.x == 0) {
-    // pairwise-free deterministic sum; numpy's pairwise sum differs by round-off only
+    // sequential like np.cumsum; numpy's pairwise .sum() differs by round-off only
     double s = 0.0, mx = 0.0;
     for (int i = 0; i < n; ++i) s += f[i];
     for (int i = 0; i < n; ++i) {
@@ -266,7 +284,9 @@ __global__ void k_day_prep(ModelParams mp, const double* start_time, const Perio
                            DayInfo* dinfo, const int* day_idx) {
   const int d = blockIdx.x;
   const int T = mp.T, N = mp.N;
-  const PeriodInfo* pi = pinfo + (int64_t)d * T;
+  extern __shared__ PeriodInfo dp_lds[];  // [T]
+  PeriodInfo* pi = dp_lds;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) pi[t] = pinfo[(int64_t)d * T + t];
   __shared__ int s_box[4];
   __shared__ int s_hl;
   if (threadIdx.x == 0) { s_box[0] = N; s_box[1] = -1; s_box[2] = N; s_box[3] = -1; }
@@ -331,8 +351,19 @@ __global__ void k_day_prep(ModelParams mp, const double* start_time, const Perio
 }
 
 // ---------------------------------------------------------------- accumulate
-// One workgroup per 16 x 16 pmf tile and day; periods in ascending order.
-__global__ void __launch_bounds__(256)
+// One workgroup per 16 x 16 pmf tile and day: PM_GROUPS groups of 320 threads.
+// Phase 0: all threads scan the day's windows and build the ordered list of periods that
+// touch the tile.  Phase 1: each group takes one listed period at a time and builds its
+// 17 x 17 corner grid in one round (289 <= 320 threads; the Phi factors of the 17 column /
+// 17 row edges are computed once) and the 256 cell masses; then the 256 cell owners add
+// hprob[t] * mass for the PM_GROUPS periods IN ASCENDING PERIOD ORDER -- the reference's
+// accumulation order (ParasitoidModel.py:539) is kept while PM_GROUPS periods are in
+// flight, which is what bounds the busiest (central) tiles.
+#define PM_GROUP_THREADS 320
+#define PM_GROUPS 3
+#define PM_TILE_THREADS (PM_GROUP_THREADS * PM_GROUPS)
+#define PM_NC ((PM_TS + 1) * (PM_TS + 1))
+__global__ void __launch_bounds__(PM_TILE_THREADS)
 k_stamp_tiles(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo* __restrict__ dinfo,
               double* pmf /*[nd][N][N]*/) {
   const int d = blockIdx.z;
@@ -340,40 +371,94 @@ k_stamp_tiles(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInf
   const int N = mp.N, T = mp.T;
   const int i0 = blockIdx.y * PM_TS, j0 = blockIdx.x * PM_TS;
   if (i0 > di.r1 || i0 + PM_TS - 1 < di.r0 || j0 > di.c1 || j0 + PM_TS - 1 < di.c0) return;
-  __shared__ double s_b[(PM_TS + 1) * (PM_TS + 1)];
-  const int tid = threadIdx.x;
-  const int li = tid / PM_TS, lj = tid % PM_TS;
-  const int i = i0 + li, j = j0 + lj;
+  extern __shared__ int st_list[];  // [T] ordered period indices touching this tile
+  __shared__ double s_b[PM_GROUPS][PM_NC];
+  __shared__ double s_px[PM_GROUPS][PM_TS + 1], s_py[PM_GROUPS][PM_TS + 1];   // Phi(-h_a), Phi(-k_b)
+  __shared__ double s_hx[PM_GROUPS][PM_TS + 1], s_ky[PM_GROUPS][PM_TS + 1];   // h_a, k_b
+  __shared__ double s_mass[PM_GROUPS][PM_TS * PM_TS];
+  __shared__ int s_wcnt[PM_TILE_THREADS / 64], s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const PeriodInfo* pi = pinfo + (int64_t)d * T;
-  const double c = mp.cell;
-  double acc = 0.0;
-  for (int t = 0; t < T; ++t) {
-    const PeriodInfo p = pi[t];
-    if (p.skip) continue;
-    const int H = p.H;
-    // window / tile overlap (uniform across the block)
-    if (p.rc + H < i0 || p.rc - H > i0 + PM_TS - 1 || p.cc + H < j0 || p.cc - H > j0 + PM_TS - 1) continue;
-    // corner grid: x corners a = 0..TS at column j0+a, y corners b = 0..TS at row i0+b
-    for (int q = tid; q < (PM_TS + 1) * (PM_TS + 1); q += 256) {
-      const int b = q / (PM_TS + 1), a = q % (PM_TS + 1);
-      const double x = (j0 + a - p.cc) * c - c / 2;        // lower x edge of column j0+a
-      const double y = (p.rc - (i0 + b)) * c + c / 2;       // upper y edge of row i0+b
-      s_b[q] = pm_bvu(mp.rule, (x - p.mux) / mp.sdx, (y - p.muy) / mp.sdy);
+  // ---- phase 0: ordered compaction of the overlapping periods
+  int nlist = 0;
+  for (int t0 = 0; t0 < T; t0 += PM_TILE_THREADS) {
+    const int t = t0 + tid;
+    bool hit = false;
+    if (t < T) {
+      const PeriodInfo p = pi[t];
+      hit = !p.skip && !(p.rc + p.H < i0 || p.rc - p.H > i0 + PM_TS - 1 || p.cc + p.H < j0 ||
+                         p.cc - p.H > j0 + PM_TS - 1);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = nlist;
+    for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+    if (hit) st_list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < PM_TILE_THREADS / 64; ++w) tot += s_wcnt[w];
+      s_total = tot;
     }
     __syncthreads();
-    const int ii = j - p.cc, jj = p.rc - i;
-    if (ii >= -H && ii <= H && jj >= -H && jj <= H && i < N && j < N) {
-      // cell [xl,xu] x [yl,yu]: BVU(xl,yl) - BVU(xu,yl) - BVU(xl,yu) + BVU(xu,yu)
-      const double ll = s_b[(li + 1) * (PM_TS + 1) + lj];
-      const double ul = s_b[(li + 1) * (PM_TS + 1) + lj + 1];
-      const double lu = s_b[li * (PM_TS + 1) + lj];
-      const double uu = s_b[li * (PM_TS + 1) + lj + 1];
-      const double mass = ((ll - ul) - lu) + uu;
-      acc = __dadd_rn(acc, __dmul_rn(p.hprob, mass));
-    }
-    __syncthreads();
+    nlist += s_total;
   }
-  if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
+  // ---- phase 1
+  const int g = tid / PM_GROUP_THREADS, gt = tid - g * PM_GROUP_THREADS;
+  const int li = gt / PM_TS, lj = gt % PM_TS;   // cell of this thread inside its group (gt < 256)
+  const double c = mp.cell;
+  double acc = 0.0;                              // owned by threads tid < 256 (group 0)
+  for (int q0 = 0; q0 < nlist; q0 += PM_GROUPS) {
+    const int q = q0 + g;
+    const bool have = q < nlist;
+    PeriodInfo p;
+    if (have) p = pi[st_list[q]];
+    if (have) {
+      if (gt <= PM_TS) {            // column edges a = gt: x of the lower edge of column j0+a
+        const double x = (j0 + gt - p.cc) * c - c / 2;
+        const double h = (x - p.mux) / mp.sdx;
+        s_hx[g][gt] = h;
+        s_px[g][gt] = pm_phi(-h);
+      } else if (gt >= 64 && gt <= 64 + PM_TS) {   // row edges b: upper y edge of row i0+b
+        const int b = gt - 64;
+        const double y = (p.rc - (i0 + b)) * c + c / 2;
+        const double k = (y - p.muy) / mp.sdy;
+        s_ky[g][b] = k;
+        s_py[g][b] = pm_phi(-k);
+      }
+    }
+    __syncthreads();
+    if (have && gt < PM_NC) {
+      const int b = gt / (PM_TS + 1), a = gt % (PM_TS + 1);
+      s_b[g][gt] = pm_bvu_phi(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
+    }
+    __syncthreads();
+    if (have && gt < PM_TS * PM_TS) {
+      const int i = i0 + li, j = j0 + lj;
+      const int ii = j - p.cc, jj = p.rc - i;
+      double hm = 0.0;    // +0.0 leaves the accumulator bit-identical when the cell is outside
+      if (ii >= -p.H && ii <= p.H && jj >= -p.H && jj <= p.H && i < N && j < N) {
+        // cell [xl,xu] x [yl,yu]: BVU(xl,yl) - BVU(xu,yl) - BVU(xl,yu) + BVU(xu,yu)
+        const double ll = s_b[g][(li + 1) * (PM_TS + 1) + lj];
+        const double ul = s_b[g][(li + 1) * (PM_TS + 1) + lj + 1];
+        const double lu = s_b[g][li * (PM_TS + 1) + lj];
+        const double uu = s_b[g][li * (PM_TS + 1) + lj + 1];
+        const double mass = ((ll - ul) - lu) + uu;
+        hm = __dmul_rn(p.hprob, mass);
+      }
+      s_mass[g][gt] = hm;
+    }
+    __syncthreads();
+    if (tid < PM_TS * PM_TS) {
+      const int ng = min(PM_GROUPS, nlist - q0);
+      for (int k = 0; k < ng; ++k) acc = __dadd_rn(acc, s_mass[k][tid]);
+    }
+    // s_mass / s_b of this round are rewritten only after the next round's first barrier
+  }
+  if (tid < PM_TS * PM_TS) {
+    const int i = i0 + tid / PM_TS, j = j0 + tid % PM_TS;
+    if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
+  }
 }
 
 // sum and min of each day's pmf: partials per (day, block) then k_pmf_reduce2

@@ -75,6 +75,8 @@ static int make_rule(double sig_x, double sig_y, double rho, double* sdx, double
     R->x[i] = x[i];
     R->sn1[i] = sin(R->asr * (x[i] + 1) / 2);
     R->sn2[i] = sin(R->asr * (-x[i] + 1) / 2);
+    R->iv1[i] = 1.0 / (1 - R->sn1[i] * R->sn1[i]);
+    R->iv2[i] = 1.0 / (1 - R->sn2[i] * R->sn2[i]);
   }
   return PS_OK;
 }
@@ -83,6 +85,8 @@ extern "C" int ps_model_create(ps_model** out, int device) {
   if (!out) return ps_fail(PS_ERR_BAD_ARG, "null output handle");
   *out = nullptr;
   PS_TRY(ps_use_device(device));
+  PS_HIP(hipFuncSetAttribute((const void*)k_day_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  PS_HIP(hipFuncSetAttribute((const void*)k_hprob, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   ps_model* m = new ps_model();
   m->device = device;
   hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
@@ -114,6 +118,7 @@ extern "C" int ps_model_set_wind(ps_model* m, const double* wind, const int32_t*
                                  int ndays_wind, int T, int test_run) {
   if (!m || !wind || !day_keys || ndays_wind < 1 || T < 1) return ps_fail(PS_ERR_BAD_ARG, "set_wind: bad arguments");
   if (test_run && T != 1) return ps_fail(PS_ERR_BAD_ARG, "test_run wind must have one period");
+  if ((size_t)T * sizeof(PeriodInfo) > 120 * 1024) return ps_fail(PS_ERR_UNSUPPORTED, "more than %d periods per day", (int)(120 * 1024 / sizeof(PeriodInfo)));
   PS_HIP(hipSetDevice(m->device));
   const size_t n = (size_t)ndays_wind * T * 3;
   PS_TRY(m->wind.ensure(n));
@@ -174,16 +179,19 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
   PS_HIP(hipMemcpyAsync(m->day_idx.p, day_idx, nd * sizeof(int), hipMemcpyHostToDevice, st));
   PS_HIP(hipMemcpyAsync(m->start_time.p, start_time, nd * sizeof(double), hipMemcpyHostToDevice, st));
   PS_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(k_hprob, dim3(nd), dim3(256), 0, st, m->wind.p, mp, m->day_idx.p, m->hprob.p, m->scratch.p);
+  hipLaunchKernelGGL(k_hprob, dim3(nd), dim3(256), (size_t)3 * T * sizeof(double), st, m->wind.p, mp, m->day_idx.p,
+                     m->hprob.p, m->scratch.p);
   PS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_periods, dim3((T * 64 + 255) / 256, nd), dim3(256), 0, st, m->wind.p, m->day_keys.p, mp,
                      m->day_idx.p, m->start_time.p, m->hprob.p, m->pinfo.p);
   PS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_day_prep, dim3(nd), dim3(256), 0, st, mp, m->start_time.p, m->pinfo.p, m->dinfo.p, m->day_idx.p);
+  hipLaunchKernelGGL(k_day_prep, dim3(nd), dim3(256), (size_t)T * sizeof(PeriodInfo), st, mp, m->start_time.p,
+                     m->pinfo.p, m->dinfo.p, m->day_idx.p);
   PS_HIP(hipGetLastError());
   PS_HIP(hipMemsetAsync(m->pmf.p, 0, (size_t)nd * n2 * sizeof(double), st));
   const int nt = (N + PM_TS - 1) / PM_TS;
-  hipLaunchKernelGGL(k_stamp_tiles, dim3(nt, nt, nd), dim3(256), 0, st, mp, m->pinfo.p, m->dinfo.p, m->pmf.p);
+  hipLaunchKernelGGL(k_stamp_tiles, dim3(nt, nt, nd), dim3(PM_TILE_THREADS), (size_t)T * sizeof(int), st, mp,
+                     m->pinfo.p, m->dinfo.p, m->pmf.p);
   PS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_pmf_reduce1, dim3(nblk, nd), dim3(256), 0, st, m->pmf.p, n2, m->psum.p, m->pmin.p);
   PS_HIP(hipGetLastError());
@@ -283,7 +291,8 @@ extern "C" int ps_model_hflight(ps_model* m, int day_i, const double* hparams, d
   if (!rc) {
     e = hipMemcpy(di.p, &day_i, sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_hprob, dim3(1), dim3(256), 0, m->stream, m->wind.p, mp, di.p, hp.p, sc.p);
+      hipLaunchKernelGGL(k_hprob, dim3(1), dim3(256), (size_t)3 * T * sizeof(double), m->stream, m->wind.p, mp, di.p,
+                         hp.p, sc.p);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
