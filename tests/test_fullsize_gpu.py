@@ -1,0 +1,119 @@
+"""Full-size (BASELINE.json config 3: N = 4097, K = 2049, reference torus P = 5121) checks
+through size-independent properties, where the CPU oracle would take minutes:
+ * the benchmarked fast mode (P' = 5184) against the exact reference torus (5121 = 9*569,
+   wave-cooperative radix-569) on the same stack,
+ * mass conservation and additivity of mean / variance under convolution,
+ * linearity of the whole chain in the initial state (moderate size),
+ * r_small_vals idempotence on device results."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip_lib():
+    from parasitoids_amd import hip_lib
+    return hip_lib
+
+
+def _moments(raw):
+    idx = np.arange(raw.shape[0], dtype=np.float64)
+    s = raw.sum()
+    r, c = raw.sum(1), raw.sum(0)
+    mr, mc = (r * idx).sum() / s, (c * idx).sum() / s
+    return s, mr, mc, (r * (idx - mr) ** 2).sum() / s, (c * (idx - mc) ** 2).sum() / s
+
+
+def test_fullsize_fast_equals_exact_torus_and_moments(hip_lib):
+    from parasitoids_amd import synthetic
+    R, K, nd = 2048, 2049, 3
+    state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613)
+    fields = {}
+    for mode in ('fast', 'exact'):
+        s = hip_lib.HipSolve(state, [K, K], mode=mode)
+        assert s.pad_shape == (5121, 5121)
+        assert s.fft_len == (5184 if mode == 'fast' else 5121)
+        s.set_kernels(kernels)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        assert not any(x.flag for x in st)
+        fields[mode] = [s.dense(0, d) for d in range(nd)]
+        for x in st:
+            assert abs(x.sum + x.delta * x.nnz - 1.0) < 1e-12
+        s.close()
+    for d in range(nd):
+        assert np.abs(fields['fast'][d] - fields['exact'][d]).max() < 1e-13
+    # mean and variance add under convolution; mass is conserved
+    km = [synthetic.moments(k) for k in kernels]
+    s, mr, mc, vr, vc = _moments(fields['fast'][-1])
+    assert abs(s - 1.0) < 1e-11
+    assert abs(mr - (R + sum(m[1] - K // 2 for m in km))) < 1e-7
+    assert abs(mc - (R + sum(m[2] - K // 2 for m in km))) < 1e-7
+    assert abs(vr / sum(m[3] for m in km) - 1) < 1e-8
+    assert abs(vc / sum(m[4] for m in km) - 1) < 1e-8
+
+
+def test_chain_is_linear_in_the_state(hip_lib):
+    from parasitoids_amd import synthetic
+    R, K, nd = 256, 129, 4
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=5, sigma=(3.0, 8.0), shift=10.0)
+    N = 2 * R + 1
+    rng = np.random.default_rng(0)
+
+    def blob(seed):
+        r = np.random.default_rng(seed)
+        ij = r.integers(R - 40, R + 40, size=(200, 2))
+        return sparse.coo_matrix((r.random(200), (ij[:, 0], ij[:, 1])), shape=(N, N))
+
+    s1, s2 = blob(1), blob(2)
+    a, b = 0.3, 1.7
+    outs = []
+    for st in (s1, s2, (a * s1 + b * s2)):
+        s = hip_lib.HipSolve(st, [K, K], mode='exact')
+        s.set_kernels(kernels)
+        s.run_chain(renorm=False)
+        s.chain_stats(0, nd)
+        outs.append(s.dense(0, nd - 1))
+        s.close()
+    scale = np.abs(outs[2]).max()
+    assert np.abs(a * outs[0] + b * outs[1] - outs[2]).max() < 1e-13 * max(scale, 1.0)
+
+
+def test_r_small_vals_idempotent(hip_lib):
+    from parasitoids_amd import synthetic, CalcSol
+    state, kernels, _ = synthetic.make_stack(R=100, K=65, ndays=2, seed=3, sigma=(2.0, 5.0), shift=5.0)
+    s = hip_lib.HipSolve(state, [65, 65])
+    s.set_kernels(kernels)
+    s.run_chain(renorm=True)
+    st = s.chain_stats(0, 2)
+    sol = s.chain_solution(1, st[1])
+    again = CalcSol.r_small_vals(sol, prob_model=True)
+    assert again.nnz == sol.nnz
+    assert np.abs(again.tocsr() - sol.tocsr()).max() < 1e-16
+    s.close()
+
+
+def test_empty_and_degenerate_inputs(hip_lib):
+    N = 33
+    empty = sparse.coo_matrix((N, N))
+    s = hip_lib.HipSolve(empty, [9, 9])
+    s.fftconv2(sparse.coo_matrix(([1.0], ([4], [4])), shape=(9, 9)))
+    out = s.get_cursol([N, N])
+    assert out.nnz == 0 and not s.last_flag
+    # identity kernel (1 x 1) leaves a state unchanged
+    st = sparse.coo_matrix(([0.25, 0.75], ([3, 30], [5, 31])), shape=(N, N))
+    s.set_state(st)
+    s.set_kernels([sparse.coo_matrix(([1.0], ([0], [0])), shape=(1, 1))])
+    s.run_chain(renorm=True)
+    got = s.chain_solution(0, s.chain_stats(0, 1)[0])
+    assert np.abs(got.toarray() - st.toarray()).max() < 1e-15
+    # mass pushed over the edge raises the boundary flag and is truncated
+    shift = sparse.coo_matrix(([1.0], ([4], [8])), shape=(9, 9))      # 4 cells to the right
+    s.set_state(st)
+    s.fftconv2(shift)
+    out = s.get_cursol([N, N])
+    assert s.last_flag
+    assert abs(out.sum() - 0.25) < 1e-14 and out.toarray()[3, 9] == pytest.approx(0.25, abs=1e-15)
+    s.close()
