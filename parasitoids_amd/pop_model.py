@@ -16,7 +16,7 @@ from . import ParasitoidModel as PM
 
 class PopModel():
     def __init__(self, wind_data, days=None, domain_info=(10000.0, 400), r_number=130000,
-                 r_start=None, mode='auto', device=None, max_solvers=4):
+                 r_start=None, mode='auto', device=None, max_solvers=4, prob_model=False):
         '''wind_data: dict day -> [T,3] (PM.get_wind_data); r_dur = 1 releases (Kalbar,
         Run.py:126-138).  mode: 'exact' | 'fast' | 'auto' (DESIGN.md section 5).'''
         from . import hip_lib
@@ -24,7 +24,10 @@ class PopModel():
         self.model = PM.WindModel(wind_data, device=device)
         self.days = list(self.model.days if days is None else days)
         self.rad_dist, self.rad_res = float(domain_info[0]), int(domain_info[1])
-        self.r_number = r_number
+        # prob_model: the probability chain of get_solutions (renormalised pmf per day,
+        # CalcSol.py:191-201) instead of the population chain of get_populations
+        self.prob_model = prob_model
+        self.r_number = 1.0 if prob_model else r_number
         self.r_start = r_start
         self.mode = mode
         self.device = device
@@ -69,7 +72,7 @@ class PopModel():
         out = [(st0.nnz, st0.sum * scale)]
         if nd > 1:
             solver.set_kernels_from_model(self.model, 1, nd - 1)
-            solver.run_chain(0, nd - 1, negval=1e-8, scale=scale, renorm=False)
+            solver.run_chain(0, nd - 1, negval=1e-8, scale=scale, renorm=self.prob_model)
             self.stats = solver.chain_stats(0, nd - 1)
             out += [(s.nnz, s.sum) for s in self.stats]
         return out
@@ -83,7 +86,19 @@ class PopModel():
             st = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
             return solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, scale, st.nnz).tocsr()
         st = self.stats[day - 1]
-        return solver._fetch(L.REC_CHAIN, day - 1, 1e-8, scale, 0.0, 1.0, st.nnz).tocsr()
+        return solver._fetch(L.REC_CHAIN, day - 1, 1e-8, scale, st.delta, 1.0, st.nnz).tocsr()
+
+    def moments(self, day):
+        '''(total, mean_row, mean_col, var_row, var_col) of one day's raw field, in cells.'''
+        solver = self.solver
+        kind, idx = (L.REC_STATE, 0) if day == 0 else (L.REC_CHAIN, day - 1)
+        raw = solver.dense(kind, idx)
+        ix = np.arange(raw.shape[0], dtype=np.float64)
+        tot = raw.sum()
+        r, c = raw.sum(1), raw.sum(0)
+        mr, mc = (r * ix).sum() / tot, (c * ix).sum() / tot
+        return (tot * self.r_number, mr, mc, (r * (ix - mr) ** 2).sum() / tot,
+                (c * (ix - mc) ** 2).sum() / tot)
 
     def gather(self, day, rows, cols):
         '''Population density at the given cells of one day (what popdensity_grid /
