@@ -49,8 +49,11 @@ struct FftProg {
   // multiply-shift reciprocals (ps_magic) of the divisors used by bf_decode
   uint32_t mg_m[PS_MAX_STAGES], mg_mh[PS_MAX_STAGES], mg_nbf[PS_MAX_STAGES], mg_Lb, mg_La;
   int32_t tw_shift, n_lo, n_hi;  // w_L^t = tw_hi[t >> shift] * tw_lo[t & mask]
+  // per-stage table w_r^t (t < r) of a wave-cooperative prime radix: offset into the
+  // block that follows tw_hi (the three tables are contiguous: lo | hi | gen), or -1
+  int32_t n_gen, gen_off[PS_MAX_STAGES];
   const cplx* tw_lo;             // device
-  const cplx* tw_hi;             // device
+  const cplx* tw_hi;             // device (= tw_lo + n_lo)
   const uint32_t* pos;           // device: digit-reversed logical position of k
   const uint32_t* pos_phys;      // device: row-mode physical position of k
 };
@@ -345,23 +348,47 @@ PS_HD void run_stage_r(cplx* data, const cplx* tlo, const cplx* thi, const FftPr
 }
 
 // ------------------------------------------------ wave-cooperative prime stage
-// A wave owns G = max(1, 64 / r) butterflies at a time; lane computes outputs
-// k = sub-lane + 64 u.  All lanes finish reading the r inputs (uniform q loop)
-// before any lane stores, so the update is in place.  Split in two calls so the
-// host emulation can order "all lanes compute" before "all lanes store".
+// Odd prime radix r (11 <= r <= 1024).  A wave owns G = max(1, 64 / r) butterflies at a
+// time; lane computes outputs k = sub-lane + 64 u from the symmetric form
+//   y_k = x_0 + sum_{q=1}^{(r-1)/2} [ (x_q + x_{r-q}) cos(2 pi q k / r)
+//                                     -+ i (x_q - x_{r-q}) sin(2 pi q k / r) ],
+// i.e. real multiplies against the stage's w_r^t table in LDS.  All lanes finish reading
+// the r inputs (uniform q loop) before any lane stores, so the update is in place.  The
+// inverse applies its input twiddles element-wise beforehand (gen_pretwiddle + barrier).
+// Split in compute/store calls so the host emulation can order "all lanes compute"
+// before "all lanes store".
 struct GenAcc {
   cplx acc[PS_GEN_KPL];
   int addr0, qstride, k0, active;
 };
 
+// inverse only: x_q *= conj(w_n^(j q)) for every element of the stage (once per element)
 template <int DIR>
-PS_HD void gen_compute(GenAcc& g, const cplx* data, const cplx* tlo, const cplx* thi,
-                       const FftProg& P, int s, int mode, int nb, int wsh, int bs,
-                       int group0, int lane) {
+PS_HD void gen_pretwiddle(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P, int s,
+                          int mode, int nb, int wsh, int bs, int tid, int nthr) {
+  if (DIR != PS_INV || P.m[s] <= 1) return;
+  const int r = P.radix[s];
+  const int nbutter = P.m[s] * P.step[s] * nb;
+  const int step = P.step[s];
+  const int tot = nbutter * (r - 1);
+  const uint32_t mg = ps_magic((uint32_t)(r - 1));
+  for (int it = tid; it < tot; it += nthr) {
+    const int bid = ps_div(it, mg);
+    const int q = it - bid * (r - 1) + 1;
+    const BfAddr a = bf_decode(P, s, mode, bid, wsh, bs);
+    if (a.j == 0) continue;
+    const int e = a.addr0 + q * a.qstride;
+    data[e] = cmulc(data[e], tw_lookup(tlo, thi, P.tw_shift, a.j * q * step));
+  }
+}
+
+template <int DIR, int KPL>
+PS_HD void gen_compute_k(GenAcc& g, const cplx* data, const cplx* tlo, const cplx* thi,
+                         const FftProg& P, int s, int mode, int nb, int wsh, int bs,
+                         int group0, int lane) {
   const int r = P.radix[s];
   const int nbutter = P.m[s] * P.step[s] * nb;
   const int G = r < 64 ? 64 / r : 1;
-  const int kpl = (r + 63) / 64;
   int sub = 0, k0 = lane;
   if (r < 64) {
     sub = lane / r;
@@ -374,34 +401,59 @@ PS_HD void gen_compute(GenAcc& g, const cplx* data, const cplx* tlo, const cplx*
   const BfAddr a = bf_decode(P, s, mode, bid, wsh, bs);
   g.addr0 = a.addr0;
   g.qstride = a.qstride;
-  const int step = P.step[s];
-  const int rstep = P.m[s] * P.step[s];
-  int idx[PS_GEN_KPL];
-  for (int u = 0; u < kpl; ++u) {
-    g.acc[u] = make_double2(0.0, 0.0);
+  const cplx* wr = thi + P.n_hi + P.gen_off[s];  // w_r^t = (cos, -sin)(2 pi t / r)
+  const cplx x0 = data[a.addr0];
+  cplx acc[KPL];
+  int idx[KPL], kk[KPL];
+#pragma unroll
+  for (int u = 0; u < KPL; ++u) {
+    acc[u] = x0;
     idx[u] = 0;
+    kk[u] = k0 + 64 * u;
+    if (kk[u] >= r) kk[u] = 0;  // parked lanes recompute output 0; never stored
   }
-  for (int q = 0; q < r; ++q) {
-    cplx xq = data[a.addr0 + q * a.qstride];
-    if (DIR == PS_INV && a.j != 0 && q != 0)
-      xq = cmulc(xq, tw_lookup(tlo, thi, P.tw_shift, a.j * q * step));
-    for (int u = 0; u < kpl; ++u) {
-      const int k = k0 + 64 * u;
-      if (k < r) {
-        cplx wr = tw_lookup(tlo, thi, P.tw_shift, idx[u] * rstep);
-        g.acc[u] = cadd(g.acc[u], DIR == PS_FWD ? cmul(xq, wr) : cmulc(xq, wr));
-        idx[u] += k;
-        if (idx[u] >= r) idx[u] -= r;
+  const int h = (r - 1) / 2;
+  for (int q = 1; q <= h; ++q) {
+    const cplx xa = data[a.addr0 + q * a.qstride];
+    const cplx xb = data[a.addr0 + (r - q) * a.qstride];
+    const cplx sa = cadd(xa, xb), sb = csub(xa, xb);
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+      idx[u] += kk[u];
+      if (idx[u] >= r) idx[u] -= r;
+      const cplx w = wr[idx[u]];
+      const double c = w.x, sn = -w.y;  // cos, sin of 2 pi q k / r
+      if (DIR == PS_FWD) {
+        acc[u].x += sa.x * c + sb.y * sn;
+        acc[u].y += sa.y * c - sb.x * sn;
+      } else {
+        acc[u].x += sa.x * c - sb.y * sn;
+        acc[u].y += sa.y * c + sb.x * sn;
       }
     }
   }
   if (DIR == PS_FWD && a.j != 0) {
-    for (int u = 0; u < kpl; ++u) {
+    const int step = P.step[s];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
       const int k = k0 + 64 * u;
-      if (k < r && k != 0)
-        g.acc[u] = cmul(g.acc[u], tw_lookup(tlo, thi, P.tw_shift, a.j * k * step));
+      if (k < r && k != 0) acc[u] = cmul(acc[u], tw_lookup(tlo, thi, P.tw_shift, a.j * k * step));
     }
   }
+#pragma unroll
+  for (int u = 0; u < KPL; ++u) g.acc[u] = acc[u];
+}
+
+template <int DIR>
+PS_HD void gen_compute(GenAcc& g, const cplx* data, const cplx* tlo, const cplx* thi,
+                       const FftProg& P, int s, int mode, int nb, int wsh, int bs,
+                       int group0, int lane) {
+  const int kpl = (P.radix[s] + 63) / 64;
+  if (kpl <= 1) gen_compute_k<DIR, 1>(g, data, tlo, thi, P, s, mode, nb, wsh, bs, group0, lane);
+  else if (kpl <= 2) gen_compute_k<DIR, 2>(g, data, tlo, thi, P, s, mode, nb, wsh, bs, group0, lane);
+  else if (kpl <= 4) gen_compute_k<DIR, 4>(g, data, tlo, thi, P, s, mode, nb, wsh, bs, group0, lane);
+  else if (kpl <= 8) gen_compute_k<DIR, 8>(g, data, tlo, thi, P, s, mode, nb, wsh, bs, group0, lane);
+  else gen_compute_k<DIR, 16>(g, data, tlo, thi, P, s, mode, nb, wsh, bs, group0, lane);
 }
 
 PS_HD void gen_store(const GenAcc& g, cplx* data, int r) {

@@ -84,9 +84,11 @@ struct RowInvArgs {
 };
 
 // -------------------------------------------------------------- LDS helpers
+// twiddle block of a program in LDS: lo | hi | gen (contiguous in HBM too)
+__device__ __forceinline__ int tw_count(const FftProg& P) { return P.n_lo + P.n_hi + P.n_gen; }
 __device__ __forceinline__ void load_tw(cplx* tlo, cplx* thi, const FftProg& P) {
-  for (int t = threadIdx.x; t < P.n_lo; t += blockDim.x) tlo[t] = P.tw_lo[t];
-  for (int t = threadIdx.x; t < P.n_hi; t += blockDim.x) thi[t] = P.tw_hi[t];
+  const int n = tw_count(P);
+  for (int t = threadIdx.x; t < n; t += blockDim.x) tlo[t] = P.tw_lo[t];
 }
 
 template <int DIR, bool GEN>
@@ -103,7 +105,13 @@ __device__ __forceinline__ void run_stage_sel(cplx* data, const cplx* tlo, const
     case 8: run_stage_r<8, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     case 9: run_stage_r<9, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     default:
-      if (GEN) run_stage_generic<DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr);
+      if (GEN) {
+        if (DIR == PS_INV && P.m[s] > 1) {   // uniform: input twiddles once per element
+          gen_pretwiddle<DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr);
+          __syncthreads();
+        }
+        run_stage_generic<DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr);
+      }
       break;
   }
 }
@@ -234,7 +242,7 @@ __global__ void k_col(ColArgs a) {
   cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
   cplx* tlo = data + ((size_t)L << a.wsh);
   cplx* thi = tlo + P.n_lo;
-  cplx* stw = thi + P.n_hi;                          // [L] 4-step twiddle of tile row
+  cplx* stw = tlo + tw_count(P);                     // [L] 4-step twiddle of tile row
   int* spos = reinterpret_cast<int*>(stw + L);       // [L] digit-reversed LDS row
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
   const int tile = blockIdx.x % ntiles;
@@ -323,7 +331,7 @@ __global__ void k_col_fused(ColFusedArgs a) {
   cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
   cplx* tlo = data + ((size_t)L << a.wsh);
   cplx* thi = tlo + P.n_lo;
-  int* spos = reinterpret_cast<int*>(thi + P.n_hi);
+  int* spos = reinterpret_cast<int*>(tlo + tw_count(P));
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
   const int tile = blockIdx.x % ntiles;
   const int o = blockIdx.x / ntiles;
@@ -394,7 +402,7 @@ __global__ void k_row_inv(RowInvArgs a) {
   cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
   cplx* tlo = data + (size_t)a.rp * pitch;
   cplx* thi = tlo + P.n_lo;
-  double* red = reinterpret_cast<double*>(thi + P.n_hi);  // 4 * (blockDim/64) doubles
+  double* red = reinterpret_cast<double*>(tlo + tw_count(P));  // 4 * (blockDim/64) doubles
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   const int pair0 = blockIdx.x * a.rp;
   const int nthr = blockDim.x;

@@ -12,7 +12,8 @@
 
 struct HostFftPlan {
   FftProg prog;  // device pointers left null here; filled by the uploader
-  std::vector<cplx> tw_lo, tw_hi;
+  std::vector<cplx> tw_lo, tw_hi, tw_gen;
+  std::vector<cplx> tw_all;  // lo | hi | gen, the layout the kernels keep in LDS
   std::vector<uint32_t> pos, pos_phys;
   int max_prime = 1;
 };
@@ -127,6 +128,26 @@ inline bool ps_build_plan(int L, bool row_split, HostFftPlan* out) {
     long double a = twopi * (long double)(((int64_t)u * B) % L) / (long double)L;
     hp.tw_hi[u] = make_double2((double)cosl(a), (double)-sinl(a));
   }
+  // w_r^t tables of the wave-cooperative prime radices
+  P.n_gen = 0;
+  hp.tw_gen.clear();
+  for (int s = 0; s < P.ns; ++s) {
+    P.gen_off[s] = -1;
+    const int r = P.radix[s];
+    if (r <= 9) continue;
+    for (int s2 = 0; s2 < s; ++s2)
+      if (P.radix[s2] == r) P.gen_off[s] = P.gen_off[s2];
+    if (P.gen_off[s] >= 0) continue;
+    P.gen_off[s] = (int)hp.tw_gen.size();
+    for (int t = 0; t < r; ++t) {
+      long double a = twopi * (long double)t / (long double)r;
+      hp.tw_gen.push_back(make_double2((double)cosl(a), (double)-sinl(a)));
+    }
+  }
+  P.n_gen = (int)hp.tw_gen.size();
+  hp.tw_all = hp.tw_lo;
+  hp.tw_all.insert(hp.tw_all.end(), hp.tw_hi.begin(), hp.tw_hi.end());
+  hp.tw_all.insert(hp.tw_all.end(), hp.tw_gen.begin(), hp.tw_gen.end());
   // digit reversal: k = k0 + r0 (k1 + r1 (...)) lives at sum_s k_s m_s
   hp.pos.resize(L);
   hp.pos_phys.resize(L);

@@ -66,21 +66,19 @@ struct DevBuf {
 struct DevPlan {
   HostFftPlan host;
   FftProg prog;  // with device pointers
-  DevBuf<cplx> tw_lo, tw_hi;
+  DevBuf<cplx> tw_all;  // lo | hi | gen, contiguous
   DevBuf<uint32_t> pos, pos_phys;
   bool generic = false;
   int upload() {
     prog = host.prog;
-    PS_TRY(tw_lo.ensure(host.tw_lo.size()));
-    PS_TRY(tw_hi.ensure(host.tw_hi.size()));
+    PS_TRY(tw_all.ensure(host.tw_all.size()));
     PS_TRY(pos.ensure(host.pos.size()));
     PS_TRY(pos_phys.ensure(host.pos_phys.size()));
-    PS_HIP(hipMemcpy(tw_lo.p, host.tw_lo.data(), host.tw_lo.size() * sizeof(cplx), hipMemcpyHostToDevice));
-    PS_HIP(hipMemcpy(tw_hi.p, host.tw_hi.data(), host.tw_hi.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(tw_all.p, host.tw_all.data(), host.tw_all.size() * sizeof(cplx), hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(pos.p, host.pos.data(), host.pos.size() * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(pos_phys.p, host.pos_phys.data(), host.pos_phys.size() * 4, hipMemcpyHostToDevice));
-    prog.tw_lo = tw_lo.p;
-    prog.tw_hi = tw_hi.p;
+    prog.tw_lo = tw_all.p;
+    prog.tw_hi = tw_all.p + prog.n_lo;
     prog.pos = pos.p;
     prog.pos_phys = pos_phys.p;
     generic = false;
@@ -89,8 +87,7 @@ struct DevPlan {
     return PS_OK;
   }
   void release() {
-    tw_lo.release();
-    tw_hi.release();
+    tw_all.release();
     pos.release();
     pos_phys.release();
   }

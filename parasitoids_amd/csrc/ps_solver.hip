@@ -166,7 +166,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   const int npairs = (s->Pf + 1) / 2;
   dim3 grid((npairs + a.rp - 1) / a.rp, batch);
   const int thr = row_threads(a.prog.L);
-  const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx);
+  const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, pred ? PS_PROF_REFFT : PS_PROF_ROW_FWD);
   if (s->row_plan.generic)
@@ -198,10 +198,10 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   const int W = 1 << a.wsh;
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)(ntiles * cp.n_outer), batch);
-  size_t lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.L) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+  size_t lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen + a.prog.L) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
   while (lds > (size_t)kMaxLds && a.wsh > 0) {
     --a.wsh;
-    lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.L) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+    lds = (((size_t)a.prog.L << a.wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen + a.prog.L) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
   }
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", lds);
   {
@@ -235,7 +235,7 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   const int npairs = (s->Pf + 1) / 2;
   dim3 grid((npairs + a.rp - 1) / a.rp, batch);
   const int thr = row_threads(a.prog.L);
-  const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx) +
+  const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, PS_PROF_ROW_INV);
@@ -302,7 +302,7 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   a.prog = plan->prog;
   a.wsh = col_wsh(a.prog.L);
   auto need = [&](int wsh) {
-    return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+    return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
   };
   while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 0) --a.wsh;
   if (need(a.wsh) > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", need(a.wsh));

@@ -30,17 +30,21 @@ static void emul_stage(std::vector<cplx>& data, const HostFftPlan& hp, int s, in
   bool spec = (r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 9);
   if (spec) {
     for (int tid = 0; tid < nthr; ++tid)
-      run_stage<DIR>(data.data(), hp.tw_lo.data(), hp.tw_hi.data(), P, s, mode, nb, wsh, bs, tid, nthr);
+      run_stage<DIR>(data.data(), hp.tw_all.data(), hp.tw_all.data() + P.n_lo, P, s, mode, nb, wsh, bs, tid, nthr);
   } else {
     int nbutter = (P.L / r) * nb;
     int G = r < 64 ? 64 / r : 1;
     int nwaves = nthr / 64;
+    const cplx* tlo = hp.tw_all.data();
+    const cplx* thi = tlo + P.n_lo;
+    // inverse: element-wise input twiddles first (a barrier separates the phases on the GPU)
+    for (int tid = 0; tid < nthr; ++tid)
+      gen_pretwiddle<DIR>(data.data(), tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr);
     for (int wave = 0; wave < nwaves; ++wave)
       for (int g0 = wave * G; g0 < nbutter; g0 += nwaves * G) {
         std::vector<GenAcc> acc(64);
         for (int lane = 0; lane < 64; ++lane)
-          gen_compute<DIR>(acc[lane], data.data(), hp.tw_lo.data(), hp.tw_hi.data(), P, s, mode, nb,
-                           wsh, bs, g0, lane);
+          gen_compute<DIR>(acc[lane], data.data(), tlo, thi, P, s, mode, nb, wsh, bs, g0, lane);
         for (int lane = 0; lane < 64; ++lane) gen_store(acc[lane], data.data(), r);
       }
   }
