@@ -36,6 +36,22 @@ __device__ __forceinline__ int src_map(const SrcMap& m, int i) {
   return -1;
 }
 
+// Which input rows of a pass are known to be zero (and were never written by the pass
+// before): row r is live iff it maps into the source (SrcMap) and, when a per-batch source
+// row range is given, falls inside it (day kernels are small blobs inside a K x K box).
+struct RowLive {
+  int on;              // 0: every row is live
+  SrcMap map;
+  const int* range;    // device [batch][2] inclusive source-row range, or nullptr
+};
+__device__ __forceinline__ bool row_live(const RowLive& v, int r, int batch) {
+  if (!v.on) return true;
+  const int sr = src_map(v.map, r);
+  if (sr < 0) return false;
+  if (!v.range) return true;
+  return sr >= v.range[2 * batch] && sr <= v.range[2 * batch + 1];
+}
+
 struct RowFwdArgs {
   const double* src;
   int64_t src_bstride;
@@ -46,6 +62,7 @@ struct RowFwdArgs {
   int H, ld, P;  // dst is [P][ld], H valid columns
   int rp;        // row pairs per block
   int skip_zero;  // all-zero row pairs are not written (the next pass knows they are zero)
+  const int* rowrange;  // device [batch][2] inclusive live source-row range, or nullptr
   const unsigned long long* pred;
   FftProg prog;
 };
@@ -62,7 +79,7 @@ struct ColArgs {
   const cplx* tp_lo;
   const cplx* tp_hi;
   int tp_shift;
-  int vr_n1, vr_lo2;  // input rows r with vr_n1 <= r < vr_lo2 are known zeros: not read
+  RowLive live;  // input rows known to be zero are not read
   const unsigned long long* pred;
   FftProg prog;
 };
@@ -151,11 +168,17 @@ __global__ void k_row_fwd(RowFwdArgs a) {
   const int pair0 = blockIdx.x * a.rp;
   const int nthr = blockDim.x;
   // any non-zero source row in this block?
+  const int rlo = a.rowrange ? a.rowrange[2 * blockIdx.y] : 0;
+  const int rhi = a.rowrange ? a.rowrange[2 * blockIdx.y + 1] : 0x7fffffff;
+  auto srow = [&](int r) {
+    const int sr = r < a.P ? src_map(a.rmap, r) : -1;
+    return (sr < rlo || sr > rhi) ? -1 : sr;
+  };
   bool any = false;
   for (int b = 0; b < a.rp; ++b) {
     const int ra = 2 * (pair0 + b), rb = ra + 1;
-    if (ra < a.P && src_map(a.rmap, ra) >= 0) any = true;
-    if (rb < a.P && src_map(a.rmap, rb) >= 0) any = true;
+    if (srow(ra) >= 0) any = true;
+    if (srow(rb) >= 0) any = true;
   }
   if (!any) {
     if (a.skip_zero) return;
@@ -172,8 +195,8 @@ __global__ void k_row_fwd(RowFwdArgs a) {
   load_tw(tlo, thi, P);
   for (int b = 0; b < a.rp; ++b) {
     const int ra = 2 * (pair0 + b), rb = ra + 1;
-    const int sa = ra < a.P ? src_map(a.rmap, ra) : -1;
-    const int sb = rb < a.P ? src_map(a.rmap, rb) : -1;
+    const int sa = srow(ra);
+    const int sb = srow(rb);
     const double* pa = src + (int64_t)sa * a.src_ld;
     const double* pb = src + (int64_t)sb * a.src_ld;
     for (int i0 = threadIdx.x; i0 < L; i0 += nthr * PS_UNROLL) {
@@ -271,7 +294,7 @@ __global__ void k_col(ColArgs a) {
       v[u] = make_double2(0.0, 0.0);
       v2[u] = make_double2(1.0, 0.0);
       const int grow = in_base + row * a.in_stride;
-      if (idx < tot && col < a.ncols && (grow < a.vr_n1 || grow >= a.vr_lo2)) {
+      if (idx < tot && col < a.ncols && row_live(a.live, grow, blockIdx.y)) {
         const int64_t g = (int64_t)grow * a.ld + col;
         v[u] = src[g];
         if (src2) v2[u] = src2[g];
@@ -319,7 +342,7 @@ struct ColFusedArgs {
   cplx* dst;
   int64_t src_bstride;
   int ld, ncols, wsh, L1, L2, store_prod;
-  int vr_n1, vr_lo2;  // kernel rows r with vr_n1 <= r < vr_lo2 are known zeros: not read
+  RowLive live;      // kernel rows known to be zero are not read
   FftProg prog;      // length L2
 };
 
@@ -349,7 +372,7 @@ __global__ void k_col_fused(ColFusedArgs a) {
       const int idx = idx0 + u * nthr;
       const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
       v[u] = make_double2(0.0, 0.0);
-      if (idx < tot && col < a.ncols && (base + row < a.vr_n1 || base + row >= a.vr_lo2))
+      if (idx < tot && col < a.ncols && row_live(a.live, (int)(base + row), 0))
         v[u] = src[(base + row) * a.ld + col];
     }
 #pragma unroll

@@ -80,7 +80,9 @@ struct ps_solver {
   DevBuf<DayStats> dstats;
   int nstat = 0;
   int last_renorm = 0;
-  int kt_vr_n1 = 0x7fffffff, kt_vr_lo2 = 0x7fffffff;  // zero-row window of the kernel transforms
+  RowLive kt_live{0, {0, 0, 0, 0}, nullptr};  // live rows of the kernel transforms (non-split fused pass)
+  DevBuf<int> krange;                         // [nk][2] live source rows of each day kernel
+  std::vector<int> hkrange;
   // staging for fetch / uploads
   DevBuf<int> orow, ocol;
   DevBuf<double> oval;
@@ -153,7 +155,7 @@ static int set_lds_attr() {
 
 static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
                           SrcMap rmap, SrcMap cmap, cplx* dst, int batch,
-                          const unsigned long long* pred, int skip_zero = 0) {
+                          const unsigned long long* pred, int skip_zero = 0, const int* rowrange = nullptr) {
   RowFwdArgs a;
   a.src = src; a.src_bstride = src_bstride; a.src_ld = src_ld;
   a.rmap = rmap; a.cmap = cmap;
@@ -163,6 +165,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   a.rp = row_pairs(a.prog);
   a.pred = pred;
   a.skip_zero = skip_zero;
+  a.rowrange = rowrange;
   const int npairs = (s->Pf + 1) / 2;
   dim3 grid((npairs + a.rp - 1) / a.rp, batch);
   const int thr = row_threads(a.prog.L);
@@ -180,7 +183,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
 template <int DIR>
 static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cplx* src2,
                       cplx* prod, cplx* dst, int batch, int64_t src2_bstride,
-                      const unsigned long long* pred, int vr_n1 = 0x7fffffff, int vr_lo2 = 0x7fffffff) {
+                      const unsigned long long* pred, RowLive live = RowLive{0, {0, 0, 0, 0}, nullptr}) {
   ColArgs a;
   a.src = src; a.src2 = src2; a.prod_dst = prod; a.dst = dst;
   const int64_t bs = (int64_t)s->Pf * s->ld;
@@ -194,7 +197,7 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   a.tw_mode = cp.tw_mode;
   a.tp_lo = s->tp_lo.p; a.tp_hi = s->tp_hi.p; a.tp_shift = s->tp_shift;
   a.pred = pred;
-  a.vr_n1 = vr_n1; a.vr_lo2 = vr_lo2;
+  a.live = live;
   const int W = 1 << a.wsh;
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)(ntiles * cp.n_outer), batch);
@@ -253,9 +256,9 @@ static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_l
   // zero source rows are neither written by the row pass nor read by the first column pass
   PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred, 1));
   if (s->fwd_passes.size() == 1) {
-    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred, rmap.n1, rmap.lo2));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred, RowLive{1, rmap, nullptr}));
   } else {
-    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred, rmap.n1, rmap.lo2));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred, RowLive{1, rmap, nullptr}));
     PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[1], s->T2.p, nullptr, nullptr, out, batch, 0, pred));
   }
   return PS_OK;
@@ -278,18 +281,19 @@ static int inv2d(ps_solver* s, const cplx* A, const cplx* B, cplx* prod, double*
 // forward transform of day kernels up to (not including) the last column sub-pass: that
 // one is fused with the spectral product and the first inverse sub-pass (k_col_fused)
 static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
-                         SrcMap rmap, SrcMap cmap, cplx* out, int batch) {
-  s->kt_vr_n1 = s->kt_vr_lo2 = 0x7fffffff;
+                         SrcMap rmap, SrcMap cmap, cplx* out, int batch, const int* rowrange = nullptr) {
+  const RowLive live{1, rmap, rowrange};
+  s->kt_live = RowLive{0, {0, 0, 0, 0}, nullptr};
   if (!s->split) {
-    s->kt_vr_n1 = rmap.n1;  // the fused pass reads the row-pass output directly
-    s->kt_vr_lo2 = rmap.lo2;
-    return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr, 1);
+    s->kt_live = live;  // the fused pass reads the row-pass output directly (one day at a time)
+    return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr, 1, rowrange);
   }
-  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, nullptr, 1));
-  return launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, nullptr, rmap.n1, rmap.lo2);
+  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, nullptr, 1, rowrange));
+  return launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, nullptr, live);
 }
 
-static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst) {
+static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst,
+                            const int* rowrange) {
   ColFusedArgs a;
   DevPlan* plan = s->split ? &s->col_plan2 : &s->col_plan1;
   a.src = kt; a.state = state; a.dst = dst;
@@ -298,7 +302,8 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   a.L1 = s->split ? s->L1 : 1;
   a.L2 = s->split ? s->L2 : s->Pf;
   a.store_prod = store_prod;
-  a.vr_n1 = s->kt_vr_n1; a.vr_lo2 = s->kt_vr_lo2;
+  a.live = s->kt_live;
+  a.live.range = rowrange;
   a.prog = plan->prog;
   a.wsh = col_wsh(a.prog.L);
   auto need = [&](int wsh) {
@@ -319,8 +324,8 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
 
 // one day step: state_hat <- state_hat * K_hat (stored when store_prod), rec <- ifft2(...)
 static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, double* rec,
-                    int stat_slot, double negval, double stat_scale) {
-  PS_TRY(launch_col_fused(s, kt, state, store_prod, s->T1.p));
+                    int stat_slot, double negval, double stat_scale, const int* rowrange = nullptr) {
+  PS_TRY(launch_col_fused(s, kt, state, store_prod, s->T1.p, rowrange));
   if (!s->split) return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
   PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
   return launch_row_inv(s, s->T2.p, rec, stat_slot, 1, negval, stat_scale);
@@ -448,7 +453,7 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
   s->tp_lo.release(); s->tp_hi.release();
   s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release();
-  s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release();
+  s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release(); s->krange.release();
   for (auto& v : s->recs)
     for (double* p : v)
       if (p) (void)hipFree(p);
@@ -550,13 +555,17 @@ static int transform_kernels(ps_solver* s, int first, int count) {
     PS_TRY(scatter_from_device(s, s->krow.p + o, s->kcol.p + o, s->kval.p + o, n,
                                s->kdense.p + (size_t)d * K * K, K, off));
   }
-  PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count));
+  PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count,
+                       s->krange.p + 2 * first));
   s->bhat_first = first;
   s->bhat_count = count;
   return PS_OK;
 }
 
-static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape) {
+// `rows`: host copy of the COO row indices, or nullptr (kernels already on the device: the
+// whole K_d box is taken as live -- prob_mass kernels are shrunk to their support)
+static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                              const int32_t* rows) {
   s->koff.assign(off, off + nk + 1);
   s->kshape.assign(kshape, kshape + nk);
   s->nk = nk;
@@ -569,6 +578,29 @@ static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const in
     s->Kmax = std::max(s->Kmax, kshape[d]);
   }
   if (2 * (s->Kmax / 2) + 1 > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "kernel larger than the pad");
+  // live rows of each kernel inside the Kmax x Kmax staging block
+  s->hkrange.assign(2 * (size_t)std::max(nk, 1), 0);
+  const int M = s->Kmax / 2;
+  for (int d = 0; d < nk; ++d) {
+    const int o = M - kshape[d] / 2;
+    int lo = 0, hi = kshape[d] - 1;
+    if (rows && off[d + 1] > off[d]) {
+      lo = kshape[d];
+      hi = -1;
+      for (int64_t i = off[d]; i < off[d + 1]; ++i) {
+        lo = std::min(lo, (int)rows[i]);
+        hi = std::max(hi, (int)rows[i]);
+      }
+    } else if (rows) {
+      lo = 1;
+      hi = 0;  // empty kernel: nothing live
+    }
+    s->hkrange[2 * d] = lo + o;
+    s->hkrange[2 * d + 1] = hi + o;
+  }
+  PS_TRY(s->krange.ensure(s->hkrange.size()));
+  PS_HIP(hipMemcpyAsync(s->krange.p, s->hkrange.data(), s->hkrange.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
   s->bhat_first = -1;
   s->bhat_count = 0;
   s->kernels_on_device = true;
@@ -593,7 +625,7 @@ extern "C" int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, co
     PS_HIP(hipMemcpyAsync(s->kval.p, val, tot * 8, hipMemcpyHostToDevice, s->stream));
     PS_HIP(hipStreamSynchronize(s->stream));
   }
-  return set_kernels_common(s, nk, off, kshape);
+  return set_kernels_common(s, nk, off, kshape, row);
 }
 
 // used by the model module (kernels already on the device)
@@ -608,7 +640,7 @@ int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, cons
     PS_HIP(hipMemcpyAsync(s->kcol.p, col, tot * 4, hipMemcpyDeviceToDevice, s->stream));
     PS_HIP(hipMemcpyAsync(s->kval.p, val, tot * 8, hipMemcpyDeviceToDevice, s->stream));
   }
-  return set_kernels_common(s, nk, off, kshape);
+  return set_kernels_common(s, nk, off, kshape, nullptr);
 }
 
 extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_scale,
@@ -628,7 +660,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     for (int d = c0; d < c0 + cn; ++d) {
       const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
       double* rec = s->recs[PS_REC_CHAIN][d];
-      PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale));
+      PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale, s->krange.p + 2 * d));
       PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
     }
   }
