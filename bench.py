@@ -108,11 +108,20 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks
+    # (ranks then share devices); the driver's runs use RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
+        os.environ['PARASITOID_DEVICE'] = str(local)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from parasitoids_amd import hip_lib, synthetic
 
@@ -163,7 +172,7 @@ def main():
     solver.prof_enable(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

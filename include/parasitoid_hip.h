@@ -124,6 +124,11 @@ int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negval, double s
                         double delta, double post_scale, int32_t* row, int32_t* col,
                         double* val, int64_t cap, int64_t* nnz_out);
 int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out /* N*N */);
+/* Point gather from a record: out[i] = v*scale at (rows[i], cols[i]), 0 where v*scale < negval
+ * -- what indexing the thresholded daily CSR solutions returns in Bayes_funcs.popdensity_grid /
+ * popdensity_to_emergence (Bayes_funcs.py:20-179), without shipping the field to the host. */
+int ps_record_gather(ps_solver* s, int kind, int idx, int64_t n, const int32_t* rows,
+                     const int32_t* cols, double scale, double negval, double* out);
 /* sum_d w[d] * record(kind[d], idx[d]) -> record (PS_REC_WSUM,0)  (CalcSol.py:322) */
 int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx,
                     const double* w);

@@ -173,3 +173,13 @@ static __global__ void k_take_half_spectrum(const double2* __restrict__ full, in
     half[(int64_t)r * ld + c] = full[(int64_t)r * P + c];
   }
 }
+
+// out[i] = rec[rows[i]][cols[i]] * scale, zeroed below negval (thresholded-solution lookup)
+static __global__ void k_gather_points(const double* __restrict__ rec, int N, const int* rows,
+                                const int* cols, int64_t n, double scale, double negval, double* out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double t = rec[(int64_t)rows[i] * N + cols[i]] * scale;
+    out[i] = (t < negval) ? 0.0 : t;
+  }
+}

@@ -59,7 +59,6 @@ struct ps_solver {
   std::vector<ColPass> fwd_passes, inv_passes;
   // spectra
   DevBuf<cplx> Ahat, Chat, T1, T2, Bhat;
-  int bhat_cap_days = 0;
   int chunk_days = 1;
   // kernels (device COO + dense staging)
   DevBuf<int> krow, kcol;
@@ -831,6 +830,28 @@ extern "C" int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* ou
   double* rec;
   PS_TRY(get_record(s, kind, idx, &rec));
   PS_HIP(hipMemcpyAsync(out, rec, (size_t)s->N * s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  return PS_OK;
+}
+
+extern "C" int ps_record_gather(ps_solver* s, int kind, int idx, int64_t n, const int32_t* rows,
+                                const int32_t* cols, double scale, double negval, double* out) {
+  if (!s || n < 0 || (n > 0 && (!rows || !cols || !out))) return ps_fail(PS_ERR_BAD_ARG, "record_gather: bad arguments");
+  if (n == 0) return PS_OK;
+  PS_HIP(hipSetDevice(s->device));
+  double* rec;
+  PS_TRY(get_record(s, kind, idx, &rec));
+  PS_TRY(check_coo(rows, cols, n, s->N, "gather point"));
+  PS_TRY(s->orow.ensure(n));
+  PS_TRY(s->ocol.ensure(n));
+  PS_TRY(s->oval.ensure(n));
+  PS_HIP(hipMemcpyAsync(s->orow.p, rows, n * 4, hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipMemcpyAsync(s->ocol.p, cols, n * 4, hipMemcpyHostToDevice, s->stream));
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_gather_points, dim3(blocks), dim3(256), 0, s->stream, rec, s->N, s->orow.p, s->ocol.p, n,
+                     scale, negval, s->oval.p);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(out, s->oval.p, n * 8, hipMemcpyDeviceToHost, s->stream));
   PS_HIP(hipStreamSynchronize(s->stream));
   return PS_OK;
 }

@@ -217,6 +217,14 @@ class HipSolve():
         k = L.i32(kinds); i = L.i32(idxs); w = L.f64(weights)
         L.check(self._lib.ps_weighted_sum(self._h, len(w), L.p_i32(k), L.p_i32(i), L.p_f64(w)))
 
+    def gather(self, kind, idx, rows, cols, scale=1.0, negval=1e-8):
+        '''Values of the thresholded record at the given cells (device gather).'''
+        r, c = L.i32(rows), L.i32(cols)
+        out = np.empty(len(r))
+        L.check(self._lib.ps_record_gather(self._h, kind, idx, len(r), L.p_i32(r), L.p_i32(c),
+                                           float(scale), float(negval), L.p_f64(out)))
+        return out
+
     def dense(self, kind, idx):
         out = np.empty((self.dom_len, self.dom_len))
         L.check(self._lib.ps_record_fetch_dense(self._h, kind, idx, L.p_f64(out)))

@@ -106,6 +106,4 @@ class PopModel():
         solver = self.solver
         scale = float(self.r_number)
         kind, idx = (L.REC_STATE, 0) if day == 0 else (L.REC_CHAIN, day - 1)
-        dense = solver.dense(kind, idx)
-        v = dense[np.asarray(rows), np.asarray(cols)] * scale
-        return np.where(v < 1e-8, 0.0, v)
+        return solver.gather(kind, idx, rows, cols, scale=scale, negval=1e-8)
