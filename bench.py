@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROF_EVERY = 7          # co-prime with the 30 days of a stack: every day position gets sampled
 
 # algorithmic bytes per launch in units of P^2 (P = reference torus N + K//2), the
 # split of SURVEY 8d's W_day = 96 P^2 over this implementation's kernels
@@ -161,7 +162,9 @@ def main():
     assert abs(stats[-1].sum + stats[-1].delta * stats[-1].nnz - 1.0) < 1e-12
     del raw
 
-    solver.prof_enable(True)
+    # HIP events bracket every PROF_EVERY-th launch of each kernel class inside the timed
+    # region (bracketing all ~250 launches per stack costs ~9 % of the throughput)
+    solver.prof_enable(os.environ.get('BENCH_NO_PROF') is None, every=PROF_EVERY)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -184,9 +187,13 @@ def main():
             if cnt:
                 avg = ms / cnt
                 alg = ALG_P2[k] * P * P
-                kern[k] = {'avg_ms': round(avg, 4), 'launches_per_step': cnt / args.steps,
+                kern[k] = {'avg_ms': round(avg, 4), 'timed_launches': cnt,
                            'alg_GBps': round(alg / (avg * 1e-3) / 1e9, 1)}
-        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['launches_per_step'])
+        if not kern:      # BENCH_NO_PROF diagnostic run
+            print(json.dumps({'value': round(value, 3), 'ms_per_step': round(dt / args.steps * 1e3, 3),
+                              'note': 'HIP-event profiling disabled'}))
+            return
+        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches'])
         ach = kern[dom]['alg_GBps']
         traffic, traffic_src = pmc_traffic(dom) if (R, K, nd) == (2048, 2049, 30) else (None, None)
         out = {

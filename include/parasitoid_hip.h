@@ -138,7 +138,7 @@ int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx
  * 3 col_inv (first pass, fused spectral product), 4 col_inv (second), 5 row_inv+epilogue,
  * 6 the three predicated passes of the flag-conditional re-FFT (no-ops when the flag is clear) */
 #define PS_PROF_NCLS 8
-int ps_prof_enable(ps_solver* s, int on);
+int ps_prof_enable(ps_solver* s, int on);   /* 0 off, 1 every launch, n > 1 every n-th launch per class */
 int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* count); /* synchronises */
 
 /* full P x P complex spectrum in/out (function-level CalcSol.fft2/fftconv2/ifft2 mirrors;

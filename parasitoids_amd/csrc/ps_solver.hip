@@ -94,7 +94,9 @@ struct ps_solver {
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[PS_PROF_NCLS] = {0};
-  long long prof_cnt[PS_PROF_NCLS] = {0};
+  long long prof_cnt[PS_PROF_NCLS] = {0};   // sampled (timed) launches
+  long long prof_seen[PS_PROF_NCLS] = {0};  // all launches
+  int prof_every = 1;                       // time every n-th launch of a class
 };
 
 static hipEvent_t prof_event(ps_solver* s) {
@@ -111,7 +113,9 @@ struct ProfScope {
   ps_solver* s;
   ps_solver::ProfRec r;
   bool on;
-  ProfScope(ps_solver* s_, int cls) : s(s_), on(s_->prof_on) {
+  ProfScope(ps_solver* s_, int cls) : s(s_), on(false) {
+    if (!s->prof_on) return;
+    on = (s->prof_seen[cls]++ % s->prof_every) == 0;
     if (!on) return;
     r.cls = cls;
     r.a = prof_event(s);
@@ -933,8 +937,9 @@ extern "C" int ps_prof_enable(ps_solver* s, int on) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(prof_drain(s));
-  for (int i = 0; i < PS_PROF_NCLS; ++i) { s->prof_ms[i] = 0; s->prof_cnt[i] = 0; }
+  for (int i = 0; i < PS_PROF_NCLS; ++i) { s->prof_ms[i] = 0; s->prof_cnt[i] = 0; s->prof_seen[i] = 0; }
   s->prof_on = on != 0;
+  s->prof_every = on > 1 ? on : 1;   // on = n > 1: time every n-th launch of each class
   return PS_OK;
 }
 

@@ -236,9 +236,10 @@ class HipSolve():
     PROF_CLASSES = ('row_fwd', 'col_fwd_a', 'col_fwd_b', 'col_inv_a', 'col_inv_b', 'row_inv',
                     'refft_pred')
 
-    def prof_enable(self, on=True):
-        '''HIP-event timing per kernel class on the solver's stream.'''
-        L.check(self._lib.ps_prof_enable(self._h, int(bool(on))))
+    def prof_enable(self, on=True, every=1):
+        '''HIP-event timing per kernel class on the solver's stream; `every` = n times only
+        every n-th launch of each class (the events themselves cost ~1 us per launch).'''
+        L.check(self._lib.ps_prof_enable(self._h, (max(1, int(every)) if on else 0)))
 
     def prof_read(self):
         '''-> {class: (total_ms, launches)} (synchronises)'''
