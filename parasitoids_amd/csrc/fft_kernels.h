@@ -63,6 +63,7 @@ struct RowFwdArgs {
   int rp;        // row pairs per block
   int skip_zero;  // all-zero row pairs are not written (the next pass knows they are zero)
   const int* rowrange;  // device [batch][2] inclusive live source-row range, or nullptr
+  int nblocks;          // work items along x (grid.x may be smaller: the kernel loops)
   const unsigned long long* pred;
   FftProg prog;
 };
@@ -80,6 +81,7 @@ struct ColArgs {
   const cplx* tp_hi;
   int tp_shift;
   RowLive live;  // input rows known to be zero are not read
+  int nblocks;   // work items along x (grid.x may be smaller: the kernel loops)
   const unsigned long long* pred;
   FftProg prog;
 };
@@ -155,8 +157,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ps_lds_raw[];
 // Two real rows (ra, rb) -> z = a + i b -> complex FFT -> A = (Z_k + conj Z_{L-k})/2,
 // B = (Z_k - conj Z_{L-k})/(2i).  Rows outside the source map are zero.
 template <bool GEN>
-__global__ void k_row_fwd(RowFwdArgs a) {
-  if (pred_skip(a.pred)) return;
+__device__ __forceinline__ void row_fwd_block(const RowFwdArgs& a, const int bx) {
   const FftProg& P = a.prog;
   const int L = P.L;
   const int pitch = row_pitch(P);
@@ -165,7 +166,7 @@ __global__ void k_row_fwd(RowFwdArgs a) {
   cplx* thi = tlo + P.n_lo;
   const double* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   cplx* dst = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
-  const int pair0 = blockIdx.x * a.rp;
+  const int pair0 = bx * a.rp;
   const int nthr = blockDim.x;
   // any non-zero source row in this block?
   const int rlo = a.rowrange ? a.rowrange[2 * blockIdx.y] : 0;
@@ -255,10 +256,20 @@ __global__ void k_row_fwd(RowFwdArgs a) {
   }
 }
 
+// Grid: a.nblocks work items; flag-conditional launches use a small grid that loops, so an
+// un-flagged day costs a ~2 us launch instead of dispatching thousands of empty workgroups.
+template <bool GEN>
+__global__ void k_row_fwd(RowFwdArgs a) {
+  if (pred_skip(a.pred)) return;
+  for (int bx = blockIdx.x; bx < a.nblocks; bx += gridDim.x) {
+    row_fwd_block<GEN>(a, bx);
+    if (bx + (int)gridDim.x < a.nblocks) __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- columns
 template <int DIR, bool GEN>
-__global__ void k_col(ColArgs a) {
-  if (pred_skip(a.pred)) return;
+__device__ __forceinline__ void col_block(const ColArgs& a, const int bx) {
   const FftProg& P = a.prog;
   const int L = P.L;
   const int W = 1 << a.wsh;
@@ -268,8 +279,8 @@ __global__ void k_col(ColArgs a) {
   cplx* stw = tlo + tw_count(P);                     // [L] 4-step twiddle of tile row
   int* spos = reinterpret_cast<int*>(stw + L);       // [L] digit-reversed LDS row
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
-  const int tile = blockIdx.x % ntiles;
-  const int o = blockIdx.x / ntiles;
+  const int tile = bx % ntiles;
+  const int o = bx / ntiles;
   const int c0 = tile << a.wsh;
   const int nthr = blockDim.x;
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
@@ -325,6 +336,15 @@ __global__ void k_col(ColArgs a) {
     cplx x = data[(lrow << a.wsh) + c];
     if (a.tw_mode == 1 && tw_on) x = cmul(x, stw[row]);
     dst[(int64_t)(out_base + row * a.out_stride) * a.ld + col] = x;
+  }
+}
+
+template <int DIR, bool GEN>
+__global__ void k_col(ColArgs a) {
+  if (pred_skip(a.pred)) return;
+  for (int bx = blockIdx.x; bx < a.nblocks; bx += gridDim.x) {
+    col_block<DIR, GEN>(a, bx);
+    if (bx + (int)gridDim.x < a.nblocks) __syncthreads();
   }
 }
 

@@ -37,6 +37,7 @@ int ps_use_device(int device) {
 }
 
 static const int kMaxLds = 160 * 1024;
+static const int kPredGrid = 512;  // grid of the flag-conditional (usually empty) launches
 #define PS_PROF_NCLS 8
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
        PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6 };
@@ -170,7 +171,8 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   a.skip_zero = skip_zero;
   a.rowrange = rowrange;
   const int npairs = (s->Pf + 1) / 2;
-  dim3 grid((npairs + a.rp - 1) / a.rp, batch);
+  a.nblocks = (npairs + a.rp - 1) / a.rp;
+  dim3 grid(pred ? std::min(a.nblocks, kPredGrid) : a.nblocks, batch);
   const int thr = row_threads(a.prog.L);
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
@@ -212,7 +214,8 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", lds);
   {
     const int W2 = 1 << a.wsh;
-    grid.x = (unsigned)(((s->H + W2 - 1) / W2) * cp.n_outer);
+    a.nblocks = ((s->H + W2 - 1) / W2) * cp.n_outer;
+    grid.x = (unsigned)(pred ? std::min(a.nblocks, kPredGrid) : a.nblocks);
   }
   ProfScope prof(s, pred ? PS_PROF_REFFT
                           : (DIR == PS_FWD ? PS_PROF_COL_FWD_A : PS_PROF_COL_INV_A) + (cp.second ? 1 : 0));

@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # the shared library is a build artefact (git-ignored): build it if this checkout has none
+    # (hipcc cross-compiles gfx950 without a GPU)
+    lib = os.path.join(ROOT, 'parasitoids_amd', 'libparasitoid_hip.so')
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'parasitoids_amd', 'csrc')], check=False)
 
 
 @pytest.fixture(scope='session')
