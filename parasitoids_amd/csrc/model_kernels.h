@@ -307,17 +307,18 @@ __global__ void k_day_prep(ModelParams mp, const double* start_time, const Perio
     if (threadIdx.x == 0) s_hl = hl;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    DayInfo di;
-    di.status = 0; di.warned = 0;
-    di.loss = 0.0;
-    const double st = start_time[d];
-    di.start_indx = st < 0 ? 0 : (int)floor(st * T);
-    const double c = mp.cell;
-    for (int t = 0; t < T; ++t) {
-      if (pi[t].skip) continue;
+  // per-period loss terms in parallel (most are exactly 0), then summed in period order by
+  // one thread so the floating-point result is the reference's sequential `loss +=`
+  double* lterm = reinterpret_cast<double*>(pi + T);   // [T], after the staged PeriodInfo
+  __shared__ int s_status, s_warned;
+  if (threadIdx.x == 0) { s_status = 0; s_warned = 0; }
+  __syncthreads();
+  const double c = mp.cell;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    double term = 0.0;
+    if (!pi[t].skip) {
       const double hp = pi[t].hprob;
-      if (!(-1e-9 <= hp && hp <= 1.000000001)) { if (!di.status) di.status = -7; }
+      if (!(-1e-9 <= hp && hp <= 1.000000001)) atomicMin(&s_status, -7);
       const int H = pi[t].H, rc = pi[t].rc, cc = pi[t].cc;
       const int rmin = rc - H, rmax = rc + H, cmin = cc - H, cmax = cc + H;
       // stamp index ranges kept after clipping (ParasitoidModel.py:508-527)
@@ -332,16 +333,27 @@ __global__ void k_day_prep(ModelParams mp, const double* start_time, const Perio
         // wasps have left the domain (ParasitoidModel.py:547-558).  Python's negative
         // slice stops make the reference raise (and warn) only for exits through
         // the top / left edge.
-        if ((rmax <= -2 && rmax >= -N) || (cmax <= -2 && cmax >= -N)) di.warned = 1;
-        di.loss += hp;
+        if ((rmax <= -2 && rmax >= -N) || (cmax <= -2 && cmax >= -N)) atomicOr(&s_warned, 1);
+        term = hp;
       } else if (clipped) {
         // sum of the kept stamp cells == rectangle probability of the kept block
         const double xl = (cs - H) * c - c / 2, xu = (ce - 1 - H) * c + c / 2;
         const double yu = (H - rs) * c + c / 2, yl = (H - (re - 1)) * c - c / 2;
         const double kept = pm_rect(mp.rule, mp.sdx, mp.sdy, pi[t].mux, pi[t].muy, xl, xu, yl, yu);
-        di.loss += (1 - kept) * hp;
+        term = (1 - kept) * hp;
       }
     }
+    lterm[t] = term;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DayInfo di;
+    di.status = s_status; di.warned = s_warned;
+    double loss = 0.0;
+    for (int t = 0; t < T; ++t) loss += lterm[t];
+    di.loss = loss;
+    const double st = start_time[d];
+    di.start_indx = st < 0 ? 0 : (int)floor(st * T);
     di.r0 = s_box[0]; di.r1 = s_box[1]; di.c0 = s_box[2]; di.c1 = s_box[3];
     di.Hl = s_hl;
     di.pmfsum = 0; di.total = 0; di.delta = 0; di.pmfmin = 0; di.ksum = 0; di.nnz = 0; di.rad = 0;

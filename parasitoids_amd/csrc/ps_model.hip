@@ -118,7 +118,7 @@ extern "C" int ps_model_set_wind(ps_model* m, const double* wind, const int32_t*
                                  int ndays_wind, int T, int test_run) {
   if (!m || !wind || !day_keys || ndays_wind < 1 || T < 1) return ps_fail(PS_ERR_BAD_ARG, "set_wind: bad arguments");
   if (test_run && T != 1) return ps_fail(PS_ERR_BAD_ARG, "test_run wind must have one period");
-  if ((size_t)T * sizeof(PeriodInfo) > 120 * 1024) return ps_fail(PS_ERR_UNSUPPORTED, "more than %d periods per day", (int)(120 * 1024 / sizeof(PeriodInfo)));
+  if ((size_t)T * (sizeof(PeriodInfo) + sizeof(double)) > 120 * 1024) return ps_fail(PS_ERR_UNSUPPORTED, "more than %d periods per day", (int)(120 * 1024 / (sizeof(PeriodInfo) + sizeof(double))));
   PS_HIP(hipSetDevice(m->device));
   const size_t n = (size_t)ndays_wind * T * 3;
   PS_TRY(m->wind.ensure(n));
@@ -185,7 +185,7 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
   hipLaunchKernelGGL(k_periods, dim3((T * 64 + 255) / 256, nd), dim3(256), 0, st, m->wind.p, m->day_keys.p, mp,
                      m->day_idx.p, m->start_time.p, m->hprob.p, m->pinfo.p);
   PS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_day_prep, dim3(nd), dim3(256), (size_t)T * sizeof(PeriodInfo), st, mp, m->start_time.p,
+  hipLaunchKernelGGL(k_day_prep, dim3(nd), dim3(256), (size_t)T * (sizeof(PeriodInfo) + sizeof(double)), st, mp, m->start_time.p,
                      m->pinfo.p, m->dinfo.p, m->day_idx.p);
   PS_HIP(hipGetLastError());
   PS_HIP(hipMemsetAsync(m->pmf.p, 0, (size_t)nd * n2 * sizeof(double), st));
