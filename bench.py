@@ -127,7 +127,7 @@ def main():
     from parasitoids_amd import hip_lib, synthetic
 
     R, K, nd = args.rad_res, args.kshape, args.ndays
-    state, kernels, params = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613 + rank)
+    state, kernels, params = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613)  # same stack on every rank
     N = 2 * R + 1
     P = N + K // 2
     solver = hip_lib.HipSolve(state, [K, K], mode=args.mode, device=local)
