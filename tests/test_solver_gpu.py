@@ -136,3 +136,44 @@ def test_errors(hip_lib, two_arrays):
         solver.fftconv2(sparse.csr_matrix(np.ones((4, 4))))   # even kernel, CalcSol.py:58
     with pytest.raises(ValueError):
         solver.get_cursol((11, 11))
+
+
+def test_error_classes_and_auto_mode(hip_lib):
+    '''C-ABI error classes surface as HipError codes; auto mode falls back to the fast
+    size only when the reference pad cannot be planned (prime factor > 1024).'''
+    from parasitoids_amd import _lib as L
+    import ctypes as C
+    N = 1001
+    one = sparse.coo_matrix(([1.0], ([500], [500])), shape=(N, N))
+    # P = 1001 + 128 = 1129 is prime: exact is unsupported, auto picks the fast size
+    with pytest.raises(L.HipError) as ei:
+        hip_lib.HipSolve(one, [257, 257], mode='exact')
+    assert ei.value.code == L.PS_ERR_UNSUPPORTED
+    s = hip_lib.HipSolve(one, [257, 257], mode='auto')
+    assert s.mode == 'fast' and s.fft_len >= 1129 and s.pad_shape == (1129, 1129)
+    with pytest.raises(L.HipError) as ei:
+        s.run_chain(0, 1)                                  # nothing uploaded
+    assert ei.value.code == L.PS_ERR_STATE
+    with pytest.raises(L.HipError) as ei:
+        s.set_kernels([sparse.coo_matrix(([1.0], ([0], [0])), shape=(259, 259))])   # > max_shape
+    assert ei.value.code == L.PS_ERR_BAD_SHAPE
+    with pytest.raises(L.HipError) as ei:
+        s.dense(L.REC_BACK, 3)                              # record does not exist
+    assert ei.value.code == L.PS_ERR_STATE
+    s.set_kernels([sparse.coo_matrix(([0.5, 0.5], ([128, 128], [128, 130])), shape=(257, 257))])
+    s.run_chain(renorm=True)
+    st = s.chain_stats(0, 1)[0]
+    row = np.empty(1, dtype=np.int32); col = np.empty(1, dtype=np.int32); val = np.empty(1)
+    nnz = C.c_int64()
+    rc = L.load().ps_record_fetch_coo(s._h, 0, 0, 1e-8, 1.0, st.delta, 1.0, L.p_i32(row), L.p_i32(col),
+                                      L.p_f64(val), 1, C.byref(nnz))
+    assert rc == L.PS_ERR_BAD_ARG and nnz.value == 2        # capacity too small, count reported
+    got = s.chain_solution(0, st)
+    assert got.nnz == 2 and abs(got.sum() - 1.0) < 1e-15
+    assert sorted(zip(got.row.tolist(), got.col.tolist())) == [(500, 500), (500, 502)]
+    v = s.gather(0, 0, [500, 500, 0], [500, 501, 0])
+    assert abs(v[0] - 0.5) < 1e-15 and v[1] == 0.0 and v[2] == 0.0
+    s.close()
+    a = hip_lib.HipSolve(sparse.coo_matrix(([1.0], ([16], [16])), shape=(33, 33)), [9, 9], mode='auto')
+    assert a.mode == 'exact' and a.fft_len == 37               # 37 is prime but <= 1024: planned
+    a.close()
