@@ -232,6 +232,63 @@ PS_HD void bfly9(cplx* x) {
   }
 }
 
+template <int DIR>
+PS_HD void bfly16(cplx* x) {
+  // q = q0 + 4 q1 ; y_{k1 + 4 k0} = sum_q0 w16^(q0 k1) (sum_q1 x w4^(q1 k1)) w4^(q0 k0)
+  const double c = 0.92387953251128673848, sn = 0.38268343236508978178, h = 0.70710678118654752440;
+  const double sg = DIR == PS_FWD ? -1.0 : 1.0;
+  cplx u[4][4];
+#pragma unroll
+  for (int q0 = 0; q0 < 4; ++q0) {
+    cplx t[4] = {x[q0], x[q0 + 4], x[q0 + 8], x[q0 + 12]};
+    bfly4<DIR>(t);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) u[q0][k1] = t[k1];
+  }
+  u[1][1] = cmul(u[1][1], make_double2(c, sg * sn));    // w^1
+  u[1][2] = cmul(u[1][2], make_double2(h, sg * h));     // w^2
+  u[1][3] = cmul(u[1][3], make_double2(sn, sg * c));    // w^3
+  u[2][1] = cmul(u[2][1], make_double2(h, sg * h));     // w^2
+  u[2][2] = cmul_mi<DIR>(u[2][2]);                      // w^4
+  u[2][3] = cmul(u[2][3], make_double2(-h, sg * h));    // w^6
+  u[3][1] = cmul(u[3][1], make_double2(sn, sg * c));    // w^3
+  u[3][2] = cmul(u[3][2], make_double2(-h, sg * h));    // w^6
+  u[3][3] = cmul(u[3][3], make_double2(-c, -sg * sn));  // w^9
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    cplx t[4] = {u[0][k1], u[1][k1], u[2][k1], u[3][k1]};
+    bfly4<DIR>(t);
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) x[k1 + 4 * k0] = t[k0];
+  }
+}
+
+template <int DIR>
+PS_HD void bfly18(cplx* x) {
+  // even / odd DFT-9 then radix-2 combine with w18^k
+  cplx e[9], o[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    e[i] = x[2 * i];
+    o[i] = x[2 * i + 1];
+  }
+  bfly9<DIR>(e);
+  bfly9<DIR>(o);
+  const double cs[9] = {1.0, 0.93969262078590838405, 0.76604444311897803520, 0.5,
+                        0.17364817766693034885, -0.17364817766693034885, -0.5,
+                        -0.76604444311897803520, -0.93969262078590838405};
+  const double ss[9] = {0.0, 0.34202014332566873304, 0.64278760968653932632,
+                        0.86602540378443864676, 0.98480775301220805937, 0.98480775301220805937,
+                        0.86602540378443864676, 0.64278760968653932632, 0.34202014332566873304};
+  const double sg = DIR == PS_FWD ? -1.0 : 1.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const cplx t = k == 0 ? o[0] : cmul(o[k], make_double2(cs[k], sg * ss[k]));
+    x[k] = cadd(e[k], t);
+    x[k + 9] = csub(e[k], t);
+  }
+}
+
 template <int R, int DIR>
 PS_HD void bfly(cplx* x) {
   if (R == 2) bfly2<DIR>(x);
@@ -241,6 +298,8 @@ PS_HD void bfly(cplx* x) {
   else if (R == 7) bfly_odd<7, DIR>(x);
   else if (R == 8) bfly8<DIR>(x);
   else if (R == 9) bfly9<DIR>(x);
+  else if (R == 16) bfly16<DIR>(x);
+  else if (R == 18) bfly18<DIR>(x);
 }
 
 // ------------------------------------------------------------------ twiddles
@@ -310,6 +369,28 @@ PS_HD BfAddr bf_decode(const FftProg& P, int s, int mode, int item, int wsh, int
   return a;
 }
 
+// w[k] = w1^k, k = 1..R-1, by a multiplication tree of depth <= 5
+template <int R>
+PS_HD void tw_powers(cplx* w, cplx w1) {
+  w[1] = w1;
+  if (R > 2) w[2] = cmul(w[1], w[1]);
+  if (R > 3) w[3] = cmul(w[2], w[1]);
+  if (R > 4) w[4] = cmul(w[2], w[2]);
+  if (R > 5) w[5] = cmul(w[4], w[1]);
+  if (R > 6) w[6] = cmul(w[3], w[3]);
+  if (R > 7) w[7] = cmul(w[4], w[3]);
+  if (R > 8) w[8] = cmul(w[4], w[4]);
+  if (R > 9) w[9] = cmul(w[8], w[1]);
+  if (R > 10) w[10] = cmul(w[5], w[5]);
+  if (R > 11) w[11] = cmul(w[8], w[3]);
+  if (R > 12) w[12] = cmul(w[6], w[6]);
+  if (R > 13) w[13] = cmul(w[8], w[5]);
+  if (R > 14) w[14] = cmul(w[7], w[7]);
+  if (R > 15) w[15] = cmul(w[8], w[7]);
+  if (R > 16) w[16] = cmul(w[8], w[8]);
+  if (R > 17) w[17] = cmul(w[16], w[1]);
+}
+
 // ------------------------------------------------------- register-radix stage
 template <int R, int DIR>
 PS_HD void run_stage_r(cplx* data, const cplx* tlo, const cplx* thi, const FftProg& P,
@@ -324,14 +405,7 @@ PS_HD void run_stage_r(cplx* data, const cplx* tlo, const cplx* thi, const FftPr
     for (int q = 0; q < R; ++q) x[q] = data[a.addr0 + q * a.qstride];
     cplx w[R];  // w[k] = w_n^(j k)
     if (has_tw && a.j != 0) {
-      w[1] = tw_lookup(tlo, thi, P.tw_shift, a.j * step);
-      if (R > 2) w[2] = cmul(w[1], w[1]);
-      if (R > 3) w[3] = cmul(w[2], w[1]);
-      if (R > 4) w[4] = cmul(w[2], w[2]);
-      if (R > 5) w[5] = cmul(w[4], w[1]);
-      if (R > 6) w[6] = cmul(w[3], w[3]);
-      if (R > 7) w[7] = cmul(w[4], w[3]);
-      if (R > 8) w[8] = cmul(w[4], w[4]);
+      tw_powers<R>(w, tw_lookup(tlo, thi, P.tw_shift, a.j * step));
       if (DIR == PS_INV) {
 #pragma unroll
         for (int q = 1; q < R; ++q) x[q] = cmulc(x[q], w[q]);
@@ -490,6 +564,8 @@ PS_HD void run_stage(cplx* data, const cplx* tlo, const cplx* thi, const FftProg
     case 7: run_stage_r<7, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     case 8: run_stage_r<8, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     case 9: run_stage_r<9, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 16: run_stage_r<16, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 18: run_stage_r<18, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     default: run_stage_generic<DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
   }
 }

@@ -110,7 +110,7 @@ __device__ __forceinline__ void load_tw(cplx* tlo, cplx* thi, const FftProg& P) 
   for (int t = threadIdx.x; t < n; t += blockDim.x) tlo[t] = P.tw_lo[t];
 }
 
-template <int DIR, bool GEN>
+template <int DIR, bool GEN, bool BIG>
 __device__ __forceinline__ void run_stage_sel(cplx* data, const cplx* tlo, const cplx* thi,
                                               const FftProg& P, int s, int mode, int nb, int wsh,
                                               int bs) {
@@ -123,6 +123,8 @@ __device__ __forceinline__ void run_stage_sel(cplx* data, const cplx* tlo, const
     case 7: run_stage_r<7, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     case 8: run_stage_r<8, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     case 9: run_stage_r<9, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 16: if (BIG) run_stage_r<16, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
+    case 18: if (BIG) run_stage_r<18, DIR>(data, tlo, thi, P, s, mode, nb, wsh, bs, tid, nthr); break;
     default:
       if (GEN) {
         if (DIR == PS_INV && P.m[s] > 1) {   // uniform: input twiddles once per element
@@ -135,17 +137,17 @@ __device__ __forceinline__ void run_stage_sel(cplx* data, const cplx* tlo, const
   }
 }
 
-template <int DIR, bool GEN>
+template <int DIR, bool GEN, bool BIG = false>
 __device__ __forceinline__ void lds_fft(cplx* data, const cplx* tlo, const cplx* thi,
                                         const FftProg& P, int mode, int nb, int wsh, int bs) {
   if (DIR == PS_FWD) {
     for (int s = 0; s < P.ns; ++s) {
-      run_stage_sel<DIR, GEN>(data, tlo, thi, P, s, mode, nb, wsh, bs);
+      run_stage_sel<DIR, GEN, BIG>(data, tlo, thi, P, s, mode, nb, wsh, bs);
       __syncthreads();
     }
   } else {
     for (int s = P.ns - 1; s >= 0; --s) {
-      run_stage_sel<DIR, GEN>(data, tlo, thi, P, s, mode, nb, wsh, bs);
+      run_stage_sel<DIR, GEN, BIG>(data, tlo, thi, P, s, mode, nb, wsh, bs);
       __syncthreads();
     }
   }
@@ -156,7 +158,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ps_lds_raw[];
 // ------------------------------------------------------------ forward rows
 // Two real rows (ra, rb) -> z = a + i b -> complex FFT -> A = (Z_k + conj Z_{L-k})/2,
 // B = (Z_k - conj Z_{L-k})/(2i).  Rows outside the source map are zero.
-template <bool GEN>
+template <bool GEN, bool BIG>
 __device__ __forceinline__ void row_fwd_block(const RowFwdArgs& a, const int bx) {
   const FftProg& P = a.prog;
   const int L = P.L;
@@ -223,7 +225,7 @@ __device__ __forceinline__ void row_fwd_block(const RowFwdArgs& a, const int bx)
     }
   }
   __syncthreads();
-  lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_ROW, a.rp, 0, pitch);
+  lds_fft<PS_FWD, GEN, BIG>(data, tlo, thi, P, PS_MODE_ROW, a.rp, 0, pitch);
   for (int b = 0; b < a.rp; ++b) {
     const int ra = 2 * (pair0 + b), rb = ra + 1;
     if (ra >= a.P) break;
@@ -258,11 +260,11 @@ __device__ __forceinline__ void row_fwd_block(const RowFwdArgs& a, const int bx)
 
 // Grid: a.nblocks work items; flag-conditional launches use a small grid that loops, so an
 // un-flagged day costs a ~2 us launch instead of dispatching thousands of empty workgroups.
-template <bool GEN>
-__global__ void k_row_fwd(RowFwdArgs a) {
+template <bool GEN, bool BIG>
+__global__ void __launch_bounds__(BIG ? 512 : 1024) k_row_fwd(RowFwdArgs a) {
   if (pred_skip(a.pred)) return;
   for (int bx = blockIdx.x; bx < a.nblocks; bx += gridDim.x) {
-    row_fwd_block<GEN>(a, bx);
+    row_fwd_block<GEN, BIG>(a, bx);
     if (bx + (int)gridDim.x < a.nblocks) __syncthreads();
   }
 }
@@ -437,8 +439,8 @@ __global__ void k_col_fused(ColFusedArgs a) {
 // a = Re z, b = Im z.  Fused epilogue: scale by 1/P^2, write the raw domain
 // field (CalcSol.py:41), per-row threshold statistics (CalcSol.py:126-135) and
 // the max over the pad region (CalcSol.py:36-37).
-template <bool GEN>
-__global__ void k_row_inv(RowInvArgs a) {
+template <bool GEN, bool BIG>
+__global__ void __launch_bounds__(BIG ? 512 : 1024) k_row_inv(RowInvArgs a) {
   const FftProg& P = a.prog;
   const int L = P.L;
   const int pitch = row_pitch(P);
@@ -500,7 +502,7 @@ __global__ void k_row_inv(RowInvArgs a) {
     if (sqrt(2.0 * (double)a.P * e) * a.scale < 0.5e-8) return;
   }
   __syncthreads();
-  lds_fft<PS_INV, GEN>(data, tlo, thi, P, PS_MODE_ROW, a.rp, 0, pitch);
+  lds_fft<PS_INV, GEN, BIG>(data, tlo, thi, P, PS_MODE_ROW, a.rp, 0, pitch);
   double* rec = a.rec + (int64_t)blockIdx.y * a.rec_bstride;
   double* rowsum = a.rowsum + (int64_t)blockIdx.y * a.stat_bstride;
   long long* rowcnt = a.rowcnt + (int64_t)blockIdx.y * a.stat_bstride;

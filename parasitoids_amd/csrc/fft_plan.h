@@ -31,10 +31,16 @@ inline int ps_next_fast_len(int n) {
   return v;
 }
 
-inline std::vector<int> ps_factor_radices(int L, int* max_prime) {
+// `big`: also use the radix-18 / radix-16 register butterflies (fewer stages; they need
+// ~200 VGPRs, so only the row passes, which run 512-thread workgroups, ask for them)
+inline std::vector<int> ps_factor_radices(int L, int* max_prime, bool big = false) {
   std::vector<int> r;
   int n = L;
   *max_prime = 1;
+  if (big) {
+    while (n % 18 == 0 && n > 18) { r.push_back(18); n /= 18; }
+    while (n % 16 == 0) { r.push_back(16); n /= 16; }
+  }
   while (n % 9 == 0) { r.push_back(9); n /= 9; }
   while (n % 8 == 0) { r.push_back(8); n /= 8; }
   while (n % 7 == 0) { r.push_back(7); n /= 7; }
@@ -52,16 +58,24 @@ inline std::vector<int> ps_factor_radices(int L, int* max_prime) {
 
 // Build the program for length L.  `row_split`: arrange the radices into a
 // leading and a trailing group (row-mode padded layout) when L is large enough.
-inline bool ps_build_plan(int L, bool row_split, HostFftPlan* out) {
+// `forced`: use exactly these radices in this order, the first `forced_lead` of them as the
+// leading group (the specialised 3-stage row kernels need a fixed layout)
+inline bool ps_build_plan(int L, bool row_split, HostFftPlan* out, bool big = false,
+                          const std::vector<int>* forced = nullptr, int forced_lead = 0) {
   HostFftPlan& hp = *out;
   FftProg& P = hp.prog;
   P = FftProg();
   P.L = L;
-  std::vector<int> rad = ps_factor_radices(L, &hp.max_prime);
+  std::vector<int> rad = ps_factor_radices(L, &hp.max_prime, big);
+  if (forced) {
+    rad = *forced;
+    hp.max_prime = 1;
+    for (int v : rad) hp.max_prime = std::max(hp.max_prime, v);
+  }
   if (L == 1) rad.clear();
   if ((int)rad.size() > PS_MAX_STAGES) return false;
   for (int v : rad)
-    if (v > 9 && v > PS_MAX_GENERIC_RADIX) return false;
+    if (v > 18 && v > PS_MAX_GENERIC_RADIX) return false;
   // choose the trailing group: subset with product closest to sqrt(L)
   std::vector<int> lead = rad, trail;
   if (row_split && L >= 512 && rad.size() >= 2) {
@@ -86,8 +100,13 @@ inline bool ps_build_plan(int L, bool row_split, HostFftPlan* out) {
   }
   // large (generic) radices first inside each group, then descending
   auto order = [](std::vector<int>& v) { std::sort(v.begin(), v.end(), std::greater<int>()); };
-  order(lead);
-  order(trail);
+  if (forced) {
+    lead.assign(rad.begin(), rad.begin() + forced_lead);
+    trail.assign(rad.begin() + forced_lead, rad.end());
+  } else {
+    order(lead);
+    order(trail);
+  }
   P.ns = 0;
   int n = L;
   for (int v : lead) { P.radix[P.ns] = v; P.n[P.ns] = n; P.m[P.ns] = n / v; n /= v; ++P.ns; }
@@ -134,7 +153,7 @@ inline bool ps_build_plan(int L, bool row_split, HostFftPlan* out) {
   for (int s = 0; s < P.ns; ++s) {
     P.gen_off[s] = -1;
     const int r = P.radix[s];
-    if (r <= 9) continue;
+    if (r <= 9 || r == 16 || r == 18) continue;
     for (int s2 = 0; s2 < s; ++s2)
       if (P.radix[s2] == r) P.gen_off[s] = P.gen_off[s2];
     if (P.gen_off[s] >= 0) continue;

@@ -83,7 +83,7 @@ struct DevPlan {
     prog.pos_phys = pos_phys.p;
     generic = false;
     for (int s = 0; s < prog.ns; ++s)
-      if (prog.radix[s] > 9 || prog.radix[s] == 6) generic = true;
+      if (prog.radix[s] > 9 && prog.radix[s] != 16 && prog.radix[s] != 18) generic = true;
     return PS_OK;
   }
   void release() {

@@ -54,6 +54,7 @@ struct ps_solver {
   int N = 0, M = 0, Pref = 0, Pf = 0, H = 0, ld = 0, mode = 0;
   DevPlan row_plan, col_plan1, col_plan2;
   bool split = false;
+  bool row_big = false;  // row plan uses the radix-18/16 butterflies (512-thread workgroups)
   int L1 = 0, L2 = 0;
   DevBuf<cplx> tp_lo, tp_hi;
   int tp_shift = 0;
@@ -131,7 +132,7 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------ helpers
-static int row_threads(int L) { return L <= 1024 ? 256 : (L <= 2560 ? 512 : 1024); }
+static int row_threads(int L, bool big = false) { return L <= 1024 ? 256 : ((L <= 2560 || big) ? 512 : 1024); }
 static int row_pairs(const FftProg& P) {
   int rp = 2048 / std::max(1, P.L);
   rp = std::max(1, std::min(8, rp));
@@ -147,8 +148,10 @@ static int col_wsh(int L) {
 static int set_lds_attr() {
   static bool done = false;
   if (done) return PS_OK;
-  const void* ks[] = {(const void*)k_row_fwd<false>, (const void*)k_row_fwd<true>,
-                      (const void*)k_row_inv<false>, (const void*)k_row_inv<true>,
+  const void* ks[] = {(const void*)k_row_fwd<false, false>, (const void*)k_row_fwd<true, false>,
+                      (const void*)k_row_fwd<false, true>,
+                      (const void*)k_row_inv<false, false>, (const void*)k_row_inv<true, false>,
+                      (const void*)k_row_inv<false, true>,
                       (const void*)k_col<PS_FWD, false>, (const void*)k_col<PS_FWD, true>,
                       (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>,
                       (const void*)k_col_fused<false>, (const void*)k_col_fused<true>};
@@ -173,14 +176,16 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   const int npairs = (s->Pf + 1) / 2;
   a.nblocks = (npairs + a.rp - 1) / a.rp;
   dim3 grid(pred ? std::min(a.nblocks, kPredGrid) : a.nblocks, batch);
-  const int thr = row_threads(a.prog.L);
+  const int thr = row_threads(a.prog.L, s->row_big);
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, pred ? PS_PROF_REFFT : PS_PROF_ROW_FWD);
   if (s->row_plan.generic)
-    hipLaunchKernelGGL(k_row_fwd<true>, grid, dim3(thr), lds, s->stream, a);
+    hipLaunchKernelGGL((k_row_fwd<true, false>), grid, dim3(thr), lds, s->stream, a);
+  else if (s->row_big)
+    hipLaunchKernelGGL((k_row_fwd<false, true>), grid, dim3(thr), lds, s->stream, a);
   else
-    hipLaunchKernelGGL(k_row_fwd<false>, grid, dim3(thr), lds, s->stream, a);
+    hipLaunchKernelGGL((k_row_fwd<false, false>), grid, dim3(thr), lds, s->stream, a);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
@@ -243,15 +248,17 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   a.stat_bstride = s->N;
   const int npairs = (s->Pf + 1) / 2;
   dim3 grid((npairs + a.rp - 1) / a.rp, batch);
-  const int thr = row_threads(a.prog.L);
+  const int thr = row_threads(a.prog.L, s->row_big);
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, PS_PROF_ROW_INV);
   if (s->row_plan.generic)
-    hipLaunchKernelGGL(k_row_inv<true>, grid, dim3(thr), lds, s->stream, a);
+    hipLaunchKernelGGL((k_row_inv<true, false>), grid, dim3(thr), lds, s->stream, a);
+  else if (s->row_big)
+    hipLaunchKernelGGL((k_row_inv<false, true>), grid, dim3(thr), lds, s->stream, a);
   else
-    hipLaunchKernelGGL(k_row_inv<false>, grid, dim3(thr), lds, s->stream, a);
+    hipLaunchKernelGGL((k_row_inv<false, false>), grid, dim3(thr), lds, s->stream, a);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
@@ -400,7 +407,17 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     ps_solver_destroy(s);
     return rc;
   };
-  if (!ps_build_plan(s->Pf, true, &s->row_plan.host))
+  // large smooth rows: radix-18/16 stages (3 instead of 4 stages at 5184) when that removes a stage
+  {
+    HostFftPlan small, big;
+    const bool ok_s = ps_build_plan(s->Pf, true, &small), ok_b = ps_build_plan(s->Pf, true, &big, true);
+    if (ok_s && ok_b && small.max_prime <= 9 && s->Pf > 1024 && big.prog.ns < small.prog.ns &&
+        getenv("PS_NO_BIG_RADIX") == nullptr) {
+      s->row_plan.host = big;
+      s->row_big = true;
+    }
+  }
+  if (!s->row_big && !ps_build_plan(s->Pf, true, &s->row_plan.host))
     return fail(ps_fail(PS_ERR_UNSUPPORTED, "cannot plan a length-%d FFT (prime factor > %d); use PS_MODE_FAST",
                         s->Pf, PS_MAX_GENERIC_RADIX));
   if ((size_t)(row_pitch(s->row_plan.host.prog) + 512) * sizeof(cplx) > (size_t)kMaxLds)
@@ -959,3 +976,4 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
 
 int ps_solver_dom_len_internal(ps_solver* s) { return s->N; }
 int ps_solver_device_internal(ps_solver* s) { return s->device; }
+

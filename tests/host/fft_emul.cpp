@@ -27,7 +27,7 @@ static void emul_stage(std::vector<cplx>& data, const HostFftPlan& hp, int s, in
                        int wsh, int bs, int nthr) {
   const FftProg& P = hp.prog;
   int r = P.radix[s];
-  bool spec = (r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 9);
+  bool spec = (r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 9 || r == 16 || r == 18);
   if (spec) {
     for (int tid = 0; tid < nthr; ++tid)
       run_stage<DIR>(data.data(), hp.tw_all.data(), hp.tw_all.data() + P.n_lo, P, s, mode, nb, wsh, bs, tid, nthr);
@@ -50,9 +50,9 @@ static void emul_stage(std::vector<cplx>& data, const HostFftPlan& hp, int s, in
   }
 }
 
-static double run_case(int L, int mode, int nb, int wsh, bool split) {
+static double run_case(int L, int mode, int nb, int wsh, bool split, bool big = false) {
   HostFftPlan hp;
-  if (!ps_build_plan(L, split, &hp)) { printf("plan failed L=%d\n", L); return -1; }
+  if (!ps_build_plan(L, split, &hp, big)) { printf("plan failed L=%d\n", L); return -1; }
   const FftProg& P = hp.prog;
   int bs = row_pitch(P);
   int W = 1 << wsh;
@@ -111,7 +111,8 @@ int main(int argc, char** argv) {
     double e1 = run_case(L, PS_MODE_COL, 1, 2, false);
     double e2 = run_case(L, PS_MODE_ROW, 1, 0, true);
     double e3 = run_case(L, PS_MODE_ROW, 2, 0, false);
-    for (double e : {e1, e2, e3}) {
+    double e4 = run_case(L, PS_MODE_ROW, 1, 0, true, true);   // radix-18/16 plans
+    for (double e : {e1, e2, e3, e4}) {
       if (e < 0) return 2;
       worst = e > worst ? e : worst;
     }
