@@ -36,8 +36,7 @@ ALG_P2 = {
     'refft_pred': 0.0,   # flag-conditional re-FFT launches (40 P^2 per flagged day; no-ops here)
 }
 # kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
-PMC_NAME = {'row_inv': 'void k_row_inv<false>', 'col_inv_a': 'void k_col_fused<false>',
-            'col_inv_b': 'void k_col<1, false>'}
+PMC_NAME = {'row_inv': 'void k_row_inv<', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1'}
 
 
 def pmc_traffic(kernel_class):
@@ -51,7 +50,7 @@ def pmc_traffic(kernel_class):
         return None, None
     best = None
     for e in json.load(open(files[-1])):
-        if e['kernel'] == name and (best is None or e['dispatches'] > best['dispatches']):
+        if e['kernel'].startswith(name) and (best is None or e['dispatches'] > best['dispatches']):
             best = e
     if best is None:
         return None, None
