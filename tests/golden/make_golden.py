@@ -328,7 +328,68 @@ def g8():
     save('g8_back_solve', **out)
 
 
-GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8}
+def fake_locinfo():
+    """A small stand-in for Data_Import.LocInfo with exactly the attributes Bayes_funcs reads
+    (the real one needs the xlsx sheets and openpyxl).  Shared with tests/helpers.py through
+    the arrays stored in the fixture."""
+    import types
+    import pandas as pd
+    td = lambda d: pd.Timedelta(days=int(d))
+    rng = np.random.default_rng(9)
+    li = types.SimpleNamespace()
+    li.collection_datesPR = [td(3), td(6)]
+    li.emerg_grids = [[(int(r), int(c)) for r, c in rng.integers(118, 139, size=(12, 2))],
+                      [(int(r), int(c)) for r, c in rng.integers(110, 147, size=(9, 2))]]
+    li.release_DataFrames = [
+        pd.DataFrame({'datePR': [td(22), td(22), td(24), td(27)]}),
+        pd.DataFrame({'datePR': [td(25), td(28), td(28), td(30)]})]
+    li.sent_ids = ['A', 'B', 'C']
+    li.field_cells = {'A': rng.integers(100, 157, size=(40, 2)),
+                      'B': rng.integers(60, 200, size=(25, 2)),
+                      'C': rng.integers(120, 137, size=(60, 2))}
+    li.sent_DataFrames = [pd.DataFrame({'datePR': [td(23), td(26)]}),
+                          pd.DataFrame({'datePR': [td(26), td(29), td(31)]})]
+    li.grid_cells = rng.integers(100, 157, size=(30, 2))
+    li.grid_obs_datesPR = [td(2), td(5), td(6)]
+    li.card_obs_datesPR = [td(3), td(6)]
+    li.card_obs = [np.zeros((4, 6)), np.zeros((4, 9))]
+    li.step_size = [10, 25]
+    return li
+
+
+def g9():
+    """Bayes_funcs: popdensity_to_emergence / popdensity_grid / popdensity_card on the
+    reference's Kalbar R=128 population solution with a synthetic LocInfo."""
+    import Bayes_funcs as BF
+    pmfs, days = _kalbar_pmfs(128, 6)
+    N, R = 257, 128
+    ms = _max_shape(pmfs)
+    pop = quiet(CS.get_populations, [_recentre(pmfs[0], R).tocsr()], pmfs, days, 6, N, ms,
+                1, 130000, lambda day: 1.0)
+    li = fake_locinfo()
+    rel, sen = BF.popdensity_to_emergence(pop, li)
+    grid = BF.popdensity_grid(pop, li)
+    card = BF.popdensity_card(pop, li, (10000.0, 128))
+    out = {}
+    for i, a in enumerate(rel): out['rel%d' % i] = a
+    for i, a in enumerate(sen): out['sen%d' % i] = a
+    out['grid'] = grid
+    for i, a in enumerate(card): out['card%d' % i] = a
+    # the LocInfo stand-in itself (so the GPU test rebuilds the identical object)
+    out['collection_days'] = np.array([t.days for t in li.collection_datesPR])
+    for i, g in enumerate(li.emerg_grids): out['emerg_grid%d' % i] = np.array(g)
+    for i, d in enumerate(li.release_DataFrames): out['rel_dates%d' % i] = np.array([t.days for t in d['datePR']])
+    for i, d in enumerate(li.sent_DataFrames): out['sen_dates%d' % i] = np.array([t.days for t in d['datePR']])
+    for k in li.sent_ids: out['field_' + k] = li.field_cells[k]
+    out['grid_cells'] = li.grid_cells
+    out['grid_obs_days'] = np.array([t.days for t in li.grid_obs_datesPR])
+    out['card_obs_days'] = np.array([t.days for t in li.card_obs_datesPR])
+    out['card_obslen'] = np.array([a.shape[1] for a in li.card_obs])
+    out['step_size'] = np.array(li.step_size)
+    save('g9_bayes_funcs', **out)
+
+
+GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(GROUPS)

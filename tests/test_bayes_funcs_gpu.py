@@ -1,0 +1,51 @@
+"""GPU parity of the Bayes_funcs mirrors (solution -> expected observations through device
+gathers) against G9: the reference's Bayes_funcs run on the reference's Kalbar R=128
+population solution with a synthetic LocInfo stand-in (tests/golden/make_golden.py:g9)."""
+import os
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import HP, DP, DLP, MU_R, NPER
+
+pytestmark = pytest.mark.gpu
+
+
+def locinfo_from(g):
+    td = lambda d: pd.Timedelta(days=int(d))
+    li = types.SimpleNamespace()
+    li.collection_datesPR = [td(d) for d in g['collection_days']]
+    li.emerg_grids = [[tuple(rc) for rc in g['emerg_grid%d' % i]] for i in range(2)]
+    li.release_DataFrames = [pd.DataFrame({'datePR': [td(d) for d in g['rel_dates%d' % i]]}) for i in range(2)]
+    li.sent_DataFrames = [pd.DataFrame({'datePR': [td(d) for d in g['sen_dates%d' % i]]}) for i in range(2)]
+    li.sent_ids = ['A', 'B', 'C']
+    li.field_cells = {k: g['field_' + k] for k in li.sent_ids}
+    li.grid_cells = g['grid_cells']
+    li.grid_obs_datesPR = [td(d) for d in g['grid_obs_days']]
+    li.card_obs_datesPR = [td(d) for d in g['card_obs_days']]
+    li.card_obs = [np.zeros((4, int(n))) for n in g['card_obslen']]
+    li.step_size = [int(v) for v in g['step_size']]
+    return li
+
+
+def test_bayes_funcs_against_reference(golden, golden_dir):
+    from parasitoids_amd import ParasitoidModel as PM, Bayes_funcs as BF
+    from parasitoids_amd.pop_model import PopModel
+    g = golden('g9_bayes_funcs')
+    li = locinfo_from(g)
+    wd, days = PM.get_wind_data(os.path.join(golden_dir, 'data', 'kalbar'), 30, '00:00')
+    pm = PopModel(wd, days, domain_info=(10000.0, 128), r_number=130000, mode='exact')
+    pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=6)
+    rel, sen = BF.popdensity_to_emergence(pm, li)
+    for i in range(2):
+        assert rel[i].shape == g['rel%d' % i].shape and sen[i].shape == g['sen%d' % i].shape
+        np.testing.assert_allclose(rel[i], g['rel%d' % i], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(sen[i], g['sen%d' % i], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(BF.popdensity_grid(pm, li), g['grid'], rtol=1e-10, atol=1e-9)
+    card = BF.popdensity_card(pm, li, (10000.0, 128))
+    for i in range(2):
+        np.testing.assert_allclose(card[i], g['card%d' % i], rtol=1e-10, atol=1e-9)
+    assert g['grid'].max() > 1.0 and g['sen0'].max() > 1.0     # the fixture is not trivially zero
+    pm.close()
