@@ -142,7 +142,12 @@ static int col_wsh(int L) {
   int w = 4096 / std::max(1, L);
   int sh = 2;
   while ((1 << (sh + 1)) <= w && sh < 5) ++sh;
+  if (const char* e = getenv("PS_COL_WSH")) sh = atoi(e);   // tuning knob (tile width 2^sh columns)
   return sh;
+}
+static int col_threads() {
+  if (const char* e = getenv("PS_COL_THREADS")) return atoi(e);   // tuning knob
+  return 256;
 }
 
 static int set_lds_attr() {
@@ -225,9 +230,9 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   ProfScope prof(s, pred ? PS_PROF_REFFT
                           : (DIR == PS_FWD ? PS_PROF_COL_FWD_A : PS_PROF_COL_INV_A) + (cp.second ? 1 : 0));
   if (cp.plan->generic)
-    hipLaunchKernelGGL((k_col<DIR, true>), grid, dim3(256), lds, s->stream, a);
+    hipLaunchKernelGGL((k_col<DIR, true>), grid, dim3(col_threads()), lds, s->stream, a);
   else
-    hipLaunchKernelGGL((k_col<DIR, false>), grid, dim3(256), lds, s->stream, a);
+    hipLaunchKernelGGL((k_col<DIR, false>), grid, dim3(col_threads()), lds, s->stream, a);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
@@ -328,9 +333,9 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
   ProfScope prof(s, PS_PROF_COL_INV_A);
   if (plan->generic)
-    hipLaunchKernelGGL(k_col_fused<true>, grid, dim3(256), need(a.wsh), s->stream, a);
+    hipLaunchKernelGGL(k_col_fused<true>, grid, dim3(col_threads()), need(a.wsh), s->stream, a);
   else
-    hipLaunchKernelGGL(k_col_fused<false>, grid, dim3(256), need(a.wsh), s->stream, a);
+    hipLaunchKernelGGL(k_col_fused<false>, grid, dim3(col_threads()), need(a.wsh), s->stream, a);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
