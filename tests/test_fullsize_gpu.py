@@ -117,3 +117,38 @@ def test_empty_and_degenerate_inputs(hip_lib):
     assert s.last_flag
     assert abs(out.sum() - 0.25) < 1e-14 and out.toarray()[3, 9] == pytest.approx(0.25, abs=1e-15)
     s.close()
+
+
+@pytest.mark.parametrize('R,K,mode', [(600, 199, 'exact'),     # P = 1300 = 2^2 5^2 13: split columns, radix 13
+                                      (1150, 547, 'exact'),    # P = 2574 = 2 3^2 11 13: both sub-passes generic
+                                      (512, 257, 'fast'),      # P = 1153 (prime): fast size 1176, single pass
+                                      (700, 301, 'auto')])     # P = 1551 = 3 11 47: split, generic
+def test_chain_with_flags_at_awkward_sizes(hip_lib, R, K, mode):
+    '''Mid-size pads that exercise the split column transform with wave-cooperative radices,
+    with kernels that push mass over the boundary so the device-side flag and the predicated
+    re-FFT run; checked against the CPU oracle (same torus, or 5e-8 in fast mode).'''
+    from parasitoids_amd import synthetic
+    from oracle import calcsol as OC
+    nd = 4
+    state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=R + K, sigma=(6.0, 18.0),
+                                             shift=K // 2 - 60)
+    N = 2 * R + 1
+    # start near the edge so that the first days already spill
+    state = sparse.coo_matrix(([0.6, 0.4], ([40, N - 30], [N - 50, 25])), shape=(N, N))
+    ms = np.array([K, K])
+    ref = [state]
+    trace = {}
+    OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, ms, trace=trace)
+    s = hip_lib.HipSolve(state, ms, mode=mode)
+    s.set_kernels(kernels)
+    s.run_chain(renorm=True)
+    st = s.chain_stats(0, nd)
+    exact = s.mode == 'exact'
+    assert any(trace['flags']), 'fixture should raise the boundary flag'
+    tol = 1e-12 if exact else 5e-8
+    for d in range(nd):
+        np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=tol)
+        if exact:
+            assert bool(st[d].flag) == bool(trace['flags'][d])
+            assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
+    s.close()
