@@ -1,0 +1,112 @@
+// Register-resident row transforms for three-stage sizes L = 16 * R2 * R3 (5184 = 16*18*18).
+//
+// The LDS-resident row passes of fft_kernels.h need the whole row pair in LDS (83 KB at
+// L = 5184), i.e. one workgroup per CU: load, transform and store of a row pair cannot
+// overlap with anything.  Here the data lives in REGISTERS (one radix-R butterfly per
+// thread, Stockham auto-sort indexing) and LDS is only the exchange medium between stages,
+// real parts first, then imaginary parts, so a workgroup needs L*8 B (+1/16 padding) =
+// 44 KB instead of 83 KB.  The first stage takes its inputs straight from HBM (thread j reads
+// elements j + q*L/R1: coalesced), the last stage feeds the epilogue from registers (thread
+// j holds outputs j + q*L/R3: coalesced stores), so a row pair makes 4 LDS passes instead of 8.
+//
+// Stockham stage (radix r, Ns = product of the earlier radices, T = L/r), thread j < T:
+//   k = j mod Ns;  x_q = in[j + q T] * w_{Ns r}^{k q};  y = DFT_r(x);
+//   out[(j - k) r + k + q' Ns] = y_q'            -> natural order after the last stage.
+// LDS word index i lives at i + (i >> 4): with R1 = 16 every exchange access below is a
+// compile-time offset from one per-thread base and (nearly) bank-conflict free.
+//
+// Plain C++ index helpers are shared with tests/host/fft_emul.cpp.
+#pragma once
+#include "fft_core.h"
+
+template <int R1, int R2, int R3>
+struct Rs {
+  static_assert(R1 == 16, "the exchange padding assumes a radix-16 first stage");
+  static constexpr int L = R1 * R2 * R3;
+  static constexpr int T1 = L / R1, T2 = L / R2, T3 = L / R3;
+  static constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+  static constexpr int NTHR = (TMAX + 63) / 64 * 64;
+  static constexpr int RMAX = R1 > R2 ? (R1 > R3 ? R1 : R3) : (R2 > R3 ? R2 : R3);
+  static constexpr int XWORDS = L + L / 16;          // padded exchange buffer (doubles)
+  static constexpr int X1_RS = T2 + T2 / 16;         // read stride of exchange 1 (T2 % 16 == 0)
+  static constexpr int X2_RS = T3 + T3 / 16;         // read stride of exchange 2 (T3 % 16 == 0)
+  // exchange 1: stage-1 thread j writes y_q' at x1_w(j) + q'; stage-2 thread j reads x_q at
+  // x_r(j) + q * X1_RS
+  static PS_HD int x1_w(int j) { return 17 * j; }
+  static PS_HD int x_r(int j) { return j + (j >> 4); }
+  // exchange 2: stage-2 thread j (k = j & 15) writes y_q' at x2_w(j) + 17 q'; stage-3 thread j
+  // reads x_q at x_r(j) + q * X2_RS
+  static PS_HD int x2_w(int j) {
+    const int k = j & 15;
+    const int b = (j - k) * R2 + k;
+    return b + (b >> 4);
+  }
+  // twiddle exponents (of w_L) of thread j in stages 2 and 3
+  static PS_HD int tw2(int j) { return (j & 15) * R3; }
+  static PS_HD int tw3(int j) { return j; }
+};
+
+template <int R, int PART>
+PS_HD void rs_put(double* ex, int base, int stride, const cplx* x) {
+#pragma unroll
+  for (int q = 0; q < R; ++q) ex[base + q * stride] = PART ? x[q].y : x[q].x;
+}
+template <int R, int PART>
+PS_HD void rs_get(const double* ex, int base, int stride, cplx* x) {
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (PART) x[q].y = ex[base + q * stride];
+    else x[q].x = ex[base + q * stride];
+  }
+}
+
+// input twiddles w1^q (w1 = forward table value, conjugated for the inverse) + butterfly.
+// w^q = w^(4a) * w^b (q = 4a + b) from w, w^2, w^3 and w^4, w^8, w^12, w^16: at most four
+// chained products per twiddle and ~30 live registers instead of a full w[R] array.
+template <int R, int DIR>
+PS_HD void rs_stage(cplx* x, cplx w1, bool tw) {
+  static_assert(R <= 20, "twiddle generation covers q < 20");
+  if (tw) {
+    cplx lo[4], hi[5];
+    lo[1] = w1;
+    lo[2] = cmul(w1, w1);
+    lo[3] = cmul(lo[2], w1);
+    hi[1] = cmul(lo[2], lo[2]);
+    hi[2] = cmul(hi[1], hi[1]);
+    hi[3] = cmul(hi[2], hi[1]);
+    hi[4] = cmul(hi[2], hi[2]);
+#pragma unroll
+    for (int q = 1; q < R; ++q) {
+      const int a = q >> 2, b = q & 3;
+      const cplx w = a == 0 ? lo[b] : (b == 0 ? hi[a] : cmul(hi[a], lo[b]));
+      x[q] = DIR == PS_FWD ? cmul(x[q], w) : cmulc(x[q], w);
+    }
+  }
+  bfly<R, DIR>(x);
+}
+
+#if defined(__HIPCC__)
+// stages 2 and 3 with both exchanges; on entry x holds the stage-1 OUTPUT of thread j,
+// on exit the stage-3 output (natural index j + q' T3) of thread j < T3.
+template <class S, int R1, int R2, int R3, int DIR>
+__device__ __forceinline__ void rs_tail(cplx* x, double* ex, const int j, const cplx w2, const cplx w3) {
+  if (j < S::T1) rs_put<R1, 0>(ex, S::x1_w(j), 1, x);
+  __syncthreads();
+  if (j < S::T2) rs_get<R2, 0>(ex, S::x_r(j), S::X1_RS, x);
+  __syncthreads();
+  if (j < S::T1) rs_put<R1, 1>(ex, S::x1_w(j), 1, x);
+  __syncthreads();
+  if (j < S::T2) rs_get<R2, 1>(ex, S::x_r(j), S::X1_RS, x);
+  if (j < S::T2) rs_stage<R2, DIR>(x, w2, true);
+  __syncthreads();
+  if (j < S::T2) rs_put<R2, 0>(ex, S::x2_w(j), 17, x);
+  __syncthreads();
+  if (j < S::T3) rs_get<R3, 0>(ex, S::x_r(j), S::X2_RS, x);
+  __syncthreads();
+  if (j < S::T2) rs_put<R2, 1>(ex, S::x2_w(j), 17, x);
+  __syncthreads();
+  if (j < S::T3) rs_get<R3, 1>(ex, S::x_r(j), S::X2_RS, x);
+  if (j < S::T3) rs_stage<R3, DIR>(x, w3, true);
+}
+
+#endif

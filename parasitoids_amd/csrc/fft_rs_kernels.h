@@ -1,0 +1,152 @@
+// Row-pass kernels on the register-resident three-stage transform of fft_rs.h.
+// Same arguments, same results (to round-off) and the same fused epilogue as k_row_inv /
+// k_row_fwd of fft_kernels.h; one row pair per workgroup.
+#pragma once
+#include "fft_kernels.h"
+#include "fft_rs.h"
+
+
+// ------------------------------------------------------------ inverse rows
+// Half-spectrum rows (ra, rb) -> Z = A + i B (Hermitian-extended while loading) -> inverse
+// FFT -> a = Re z, b = Im z, with the epilogue of CalcSol.ifft2 / r_small_vals
+// (CalcSol.py:35-41, :126-135) applied to the last stage's registers.
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rs(RowInvArgs a) {
+  using S = Rs<R1, R2, R3>;
+  constexpr int L = S::L;
+  constexpr int NW = S::NTHR / 64;
+  double* ex = reinterpret_cast<double*>(ps_lds_raw);
+  double* red = ex + ((S::XWORDS + 15) & ~15);   // 4 * NW doubles
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
+  const int ra = 2 * blockIdx.x, rb = ra + 1;
+  const bool hasb = rb < a.P;
+  const cplx* pa = src + (int64_t)ra * a.ld;
+  const cplx* pb = src + (int64_t)(hasb ? rb : ra) * a.ld;
+  const bool pad_only = ra >= a.N;
+  const FftProg& P = a.prog;
+  const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
+  const cplx w3 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
+  cplx x[S::RMAX];
+  double energy = 0.0;
+  if (j < S::T1) {
+    // A straight into x; B in two halves, so at most 3/4 of the 2 x 16 loads hold registers
+    auto idx = [&](int q) -> unsigned {
+      const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);   // j + q T1 <= L/2
+      const unsigned i = (unsigned)j + (unsigned)(q * S::T1);
+      return direct ? i : (unsigned)L - i;
+    };
+#pragma unroll
+    for (int q = 0; q < R1; ++q) x[q] = pa[idx(q)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cplx B[R1 / 2];
+#pragma unroll
+      for (int u = 0; u < R1 / 2; ++u) B[u] = pb[idx(h * (R1 / 2) + u)];   // pb aliases row a when there is no row b
+#pragma unroll
+      for (int u = 0; u < R1 / 2; ++u) {
+        const int q = h * (R1 / 2) + u;
+        const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);
+        const cplx A = x[q];
+        if (!hasb) B[u] = make_double2(0.0, 0.0);
+        if (direct) energy += A.x * A.x + A.y * A.y + B[u].x * B[u].x + B[u].y * B[u].y;
+        x[q] = direct ? make_double2(A.x - B[u].y, A.y + B[u].x)
+                      : make_double2(A.x + B[u].y, B[u].x - A.y);
+      }
+
+    }
+  }
+  // Pad-only row pairs feed nothing but the boundary flag; Parseval bounds their largest
+  // value (see k_row_inv) and the transform is skipped when that cannot raise the flag.
+  if (pad_only) {   // uniform across the workgroup
+    for (int off = 32; off > 0; off >>= 1) energy += __shfl_down(energy, off);
+    if (lane == 0) red[wave] = energy;
+    __syncthreads();
+    double e = 0.0;
+    for (int w = 0; w < NW; ++w) e += red[w];
+    if (sqrt(2.0 * (double)a.P * e) * a.scale < 0.5e-8) return;
+    __syncthreads();
+  }
+  if (j < S::T1) bfly<R1, PS_INV>(x);
+  rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
+
+  double* rec = a.rec + (int64_t)blockIdx.y * a.rec_bstride;
+  double sa = 0.0, sb = 0.0, pmax = 0.0;
+  int ca = 0, cb = 0;
+  if (j < S::T3) {
+    // uniform row bases + 32-bit lane offsets: one address register for all 2 x R3 stores
+    double* reca = rec + (int64_t)ra * a.N;
+    double* recb = rec + (int64_t)rb * a.N;
+    const bool dom_a = ra < a.N, dom_b = rb < a.N;
+    const unsigned uj = (unsigned)j, uN = (unsigned)a.N;
+    const bool dom_ab = dom_a && dom_b;
+#pragma unroll
+    for (int q = 0; q < R3; ++q) {
+      const unsigned i = uj + (unsigned)(q * S::T3);
+      const double va = x[q].x * a.scale, vb = x[q].y * a.scale;
+      const double ta = va * a.stat_scale, tb = vb * a.stat_scale;
+      if (dom_ab && (unsigned)((q + 1) * S::T3) <= uN) {
+        // uniform fast path (almost every element): both rows and the whole chunk of
+        // columns lie inside the domain -- no pad bookkeeping, unpredicated stores
+        reca[i] = va;
+        recb[i] = vb;
+        const bool ka = !(ta < a.negval), kb = !(tb < a.negval);
+        sa += ka ? ta : 0.0;
+        sb += kb ? tb : 0.0;
+        ca += ka ? 1 : 0;
+        cb += kb ? 1 : 0;
+      } else {
+        const bool in = i < uN;
+        const bool ina = in && dom_a, inb = in && dom_b;
+        // branch-free statistics; only the two stores are predicated
+        const bool ka = ina && !(ta < a.negval), kb = inb && !(tb < a.negval);
+        sa += ka ? ta : 0.0;
+        sb += kb ? tb : 0.0;
+        ca += ka ? 1 : 0;
+        cb += kb ? 1 : 0;
+        pmax = fmax(pmax, ina ? 0.0 : va);
+        pmax = fmax(pmax, (inb || !hasb) ? 0.0 : vb);
+        if (ina) reca[i] = va;
+        if (inb) recb[i] = vb;
+      }
+    }
+  }
+  // deterministic block reduction (fixed shuffle tree, then waves in order)
+  for (int off = 32; off > 0; off >>= 1) {
+    sa += __shfl_down(sa, off);
+    sb += __shfl_down(sb, off);
+    ca += __shfl_down(ca, off);
+    cb += __shfl_down(cb, off);
+    pmax = fmax(pmax, __shfl_down(pmax, off));
+  }
+  double* redm = red + 4 * NW;
+  if (lane == 0) {
+    red[wave * 4 + 0] = sa;
+    red[wave * 4 + 1] = sb;
+    red[wave * 4 + 2] = (double)ca;
+    red[wave * 4 + 3] = (double)cb;
+    redm[wave] = pmax;
+  }
+  __syncthreads();
+  if (j == 0) {
+    double ta = 0, tb = 0, na = 0, nbb = 0, m = 0;
+    for (int w = 0; w < NW; ++w) {
+      ta += red[w * 4 + 0];
+      tb += red[w * 4 + 1];
+      na += red[w * 4 + 2];
+      nbb += red[w * 4 + 3];
+      m = fmax(m, redm[w]);
+    }
+    double* rowsum = a.rowsum + (int64_t)blockIdx.y * a.stat_bstride;
+    long long* rowcnt = a.rowcnt + (int64_t)blockIdx.y * a.stat_bstride;
+    if (ra < a.N) { rowsum[ra] = ta; rowcnt[ra] = (long long)na; }
+    if (rb < a.N) { rowsum[rb] = tb; rowcnt[rb] = (long long)nbb; }
+    unsigned long long* pm = a.padmax + blockIdx.y;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    // only maxima that can matter for the flag (> 1e-8) are published: the read-check costs a
+    // global round trip that would otherwise end every workgroup
+    if (m > 0.5e-8 && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(pm, bits);
+  }
+}
+

@@ -3,6 +3,7 @@
 // the CPU chain of CalcSol.py:140-325 with fp64 HIP kernels for gfx950.
 #include "chain_kernels.h"
 #include "fft_kernels.h"
+#include "fft_rs_kernels.h"
 #include "ps_common.h"
 
 thread_local std::string ps_tls_error;
@@ -55,6 +56,8 @@ struct ps_solver {
   DevPlan row_plan, col_plan1, col_plan2;
   bool split = false;
   bool row_big = false;  // row plan uses the radix-18/16 butterflies (512-thread workgroups)
+  int num_cu = 256;
+  int row_rs = 0;        // register-resident three-stage row kernels (fft_rs.h): 1 = 16*18*18
   int L1 = 0, L2 = 0;
   DevBuf<cplx> tp_lo, tp_hi;
   int tp_shift = 0;
@@ -258,7 +261,11 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, PS_PROF_ROW_INV);
-  if (s->row_plan.generic)
+  if (s->row_rs == 1) {
+    using S = Rs<16, 18, 18>;
+    const size_t xl = (size_t)(((S::XWORDS + 15) & ~15) + 5 * (S::NTHR / 64)) * sizeof(double);
+    hipLaunchKernelGGL((k_row_inv_rs<16, 18, 18>), dim3(npairs, batch), dim3(S::NTHR), xl, s->stream, a);
+  } else if (s->row_plan.generic)
     hipLaunchKernelGGL((k_row_inv<true, false>), grid, dim3(thr), lds, s->stream, a);
   else if (s->row_big)
     hipLaunchKernelGGL((k_row_inv<false, true>), grid, dim3(thr), lds, s->stream, a);
@@ -429,7 +436,16 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     return fail(ps_fail(PS_ERR_UNSUPPORTED, "pad size %d exceeds the LDS-resident row limit", s->Pf));
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
+  if (s->Pf == Rs<16, 18, 18>::L && getenv("PS_NO_RS") == nullptr) s->row_rs = 1;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;
+  }
   s->L1 = ps_choose_col_split(s->Pf, 1200);
+  if (const char* e = getenv("PS_COL_L1")) {   // tuning knob: first sub-pass length of the column split
+    const int l1 = atoi(e);
+    if (l1 > 1 && l1 < s->Pf && s->Pf % l1 == 0) s->L1 = l1;
+  }
   s->split = s->L1 != s->Pf;
   if (s->split) {
     s->L2 = s->Pf / s->L1;
@@ -981,4 +997,5 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
 
 int ps_solver_dom_len_internal(ps_solver* s) { return s->N; }
 int ps_solver_device_internal(ps_solver* s) { return s->device; }
+
 

@@ -4,9 +4,12 @@
 // DFT.  Usage: fft_emul L [L ...]   -> prints max relative error per case.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include <complex>
 #include "../../parasitoids_amd/csrc/fft_plan.h"
+#include "../../parasitoids_amd/csrc/fft_rs.h"
+#include <array>
 
 typedef std::complex<long double> lc;
 
@@ -104,8 +107,71 @@ static double run_case(int L, int mode, int nb, int wsh, bool split, bool big = 
   return fwd > ierr ? fwd : ierr;
 }
 
+
+// Register-resident three-stage transform (fft_rs.h): every thread keeps its butterfly in
+// x[j]; the exchange goes through a padded word buffer exactly as on the GPU (real parts,
+// then imaginary parts).  Also counts out-of-range / never-written exchange reads.
+template <int R1, int R2, int R3, int DIR>
+static double run_rs() {
+  using S = Rs<R1, R2, R3>;
+  const int L = S::L;
+  HostFftPlan hp;
+  if (!ps_build_plan(L, true, &hp)) return -1;
+  const FftProg& P = hp.prog;
+  const cplx* tlo = hp.tw_all.data();
+  const cplx* thi = tlo + P.n_lo;
+  std::vector<std::array<cplx, S::RMAX>> x(S::NTHR);
+  const double poison = 1e300;
+  std::vector<double> ex(S::XWORDS, poison);
+  std::vector<lc> in(L), ref(L);
+  srand(L * 3 + DIR);
+  for (int i = 0; i < L; ++i) in[i] = lc(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+  for (int j = 0; j < S::T1; ++j) {
+    for (int q = 0; q < R1; ++q) x[j][q] = make_double2((double)in[j + q * S::T1].real(), (double)in[j + q * S::T1].imag());
+    bfly<R1, DIR>(x[j].data());
+  }
+  auto fresh = [&]() { std::fill(ex.begin(), ex.end(), poison); };
+  fresh();
+  for (int j = 0; j < S::T1; ++j) rs_put<R1, 0>(ex.data(), S::x1_w(j), 1, x[j].data());
+  for (int j = 0; j < S::T2; ++j) rs_get<R2, 0>(ex.data(), S::x_r(j), S::X1_RS, x[j].data());
+  fresh();
+  for (int j = 0; j < S::T1; ++j) rs_put<R1, 1>(ex.data(), S::x1_w(j), 1, x[j].data());
+  for (int j = 0; j < S::T2; ++j) rs_get<R2, 1>(ex.data(), S::x_r(j), S::X1_RS, x[j].data());
+  for (int j = 0; j < S::T2; ++j)
+    rs_stage<R2, DIR>(x[j].data(), tw_lookup(tlo, thi, P.tw_shift, S::tw2(j)), true);
+  fresh();
+  for (int j = 0; j < S::T2; ++j) rs_put<R2, 0>(ex.data(), S::x2_w(j), 17, x[j].data());
+  for (int j = 0; j < S::T3; ++j) rs_get<R3, 0>(ex.data(), S::x_r(j), S::X2_RS, x[j].data());
+  fresh();
+  for (int j = 0; j < S::T2; ++j) rs_put<R2, 1>(ex.data(), S::x2_w(j), 17, x[j].data());
+  for (int j = 0; j < S::T3; ++j) rs_get<R3, 1>(ex.data(), S::x_r(j), S::X2_RS, x[j].data());
+  for (int j = 0; j < S::T3; ++j)
+    rs_stage<R3, DIR>(x[j].data(), tw_lookup(tlo, thi, P.tw_shift, S::tw3(j)), true);
+  naive(in, ref, DIR == PS_FWD ? -1 : 1);
+  double maxerr = 0, maxv = 0;
+  for (int j = 0; j < S::T3; ++j)
+    for (int q = 0; q < R3; ++q) {
+      const lc r = ref[j + q * S::T3];
+      const double dr = (double)fabsl((long double)x[j][q].x - r.real());
+      const double di = (double)fabsl((long double)x[j][q].y - r.imag());
+      maxerr = std::max(maxerr, std::max(dr, di));
+      maxv = std::max(maxv, (double)std::abs(r));
+    }
+  printf("RS L=%d (%d,%d,%d) dir=%d rel err %.3e\n", L, R1, R2, R3, DIR, maxerr / maxv);
+  return maxerr / maxv;
+}
+
 int main(int argc, char** argv) {
   double worst = 0;
+  if (argc > 1 && !strcmp(argv[1], "rs")) {
+    for (double e : {run_rs<16, 18, 18, PS_FWD>(), run_rs<16, 18, 18, PS_INV>(),
+                     run_rs<16, 9, 8, PS_FWD>(), run_rs<16, 16, 18, PS_INV>()}) {
+      if (e < 0) return 2;
+      worst = e > worst ? e : worst;
+    }
+    printf("WORST %.3e\n", worst);
+    return worst < 1e-13 ? 0 : 1;
+  }
   for (int a = 1; a < argc; ++a) {
     int L = atoi(argv[a]);
     double e1 = run_case(L, PS_MODE_COL, 1, 2, false);

@@ -69,6 +69,10 @@ def test_fft_program_emulation():
     assert out.returncode == 0, out.stdout[-2000:]
     worst = float(out.stdout.strip().split()[-1])
     assert worst < 5e-15
+    # register-resident three-stage transforms (fft_rs.h): Stockham indexing, padded exchange
+    out = subprocess.run([exe, 'rs'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert float(out.stdout.strip().split()[-1]) < 5e-15
 
 
 def test_params_defaults_and_parsing(tmp_path):
