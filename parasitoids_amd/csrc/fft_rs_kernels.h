@@ -10,16 +10,32 @@
 // Half-spectrum rows (ra, rb) -> Z = A + i B (Hermitian-extended while loading) -> inverse
 // FFT -> a = Re z, b = Im z, with the epilogue of CalcSol.ifft2 / r_small_vals
 // (CalcSol.py:35-41, :126-135) applied to the last stage's registers.
+// NP row pairs per workgroup, each on its own NTHR threads and its own exchange buffer, in
+// lockstep (shared barriers): twice the loads in flight and twice the waves to hide VALU/LDS
+// latency per CU without needing a second resident workgroup (158 registers allow 3 waves per
+// SIMD = 12 per CU, and two 6-wave workgroups are not co-scheduled).
 template <int R1, int R2, int R3>
-__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rs(RowInvArgs a) {
+struct RsInvLds {
   using S = Rs<R1, R2, R3>;
+  static constexpr int XW = (S::XWORDS + 15) & ~15;
+  static constexpr int RED = 8 * (S::NTHR / 64);
+  static constexpr size_t bytes(int np) { return (size_t)np * (XW + RED) * sizeof(double); }
+};
+
+template <int R1, int R2, int R3, int NP>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowInvArgs a) {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
   constexpr int L = S::L;
   constexpr int NW = S::NTHR / 64;
-  double* ex = reinterpret_cast<double*>(ps_lds_raw);
-  double* red = ex + ((S::XWORDS + 15) & ~15);   // 4 * NW doubles
-  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int half = threadIdx.x / S::NTHR;
+  const int pair = blockIdx.x * NP + half;
+  if (2 * pair >= a.P) return;   // ended waves do not take part in the barriers below
+  double* ex = reinterpret_cast<double*>(ps_lds_raw) + half * (Y::XW + Y::RED);
+  double* red = ex + Y::XW;      // 5 * NW doubles
+  const int j = threadIdx.x - half * S::NTHR, lane = j & 63, wave = j >> 6;
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
-  const int ra = 2 * blockIdx.x, rb = ra + 1;
+  const int ra = 2 * pair, rb = ra + 1;
   const bool hasb = rb < a.P;
   const cplx* pa = src + (int64_t)ra * a.ld;
   const cplx* pb = src + (int64_t)(hasb ? rb : ra) * a.ld;
@@ -53,19 +69,21 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rs(RowInvArg
         x[q] = direct ? make_double2(A.x - B[u].y, A.y + B[u].x)
                       : make_double2(A.x + B[u].y, B[u].x - A.y);
       }
-
     }
   }
   // Pad-only row pairs feed nothing but the boundary flag; Parseval bounds their largest
   // value (see k_row_inv) and the transform is skipped when that cannot raise the flag.
-  if (pad_only) {   // uniform across the workgroup
+  // The barrier is unconditional: the NP row pairs of a workgroup share it, and a pair that
+  // returns here simply stops counting for the later ones.
+  if (pad_only) {   // uniform per row pair
     for (int off = 32; off > 0; off >>= 1) energy += __shfl_down(energy, off);
     if (lane == 0) red[wave] = energy;
-    __syncthreads();
+  }
+  __syncthreads();
+  if (pad_only) {
     double e = 0.0;
     for (int w = 0; w < NW; ++w) e += red[w];
     if (sqrt(2.0 * (double)a.P * e) * a.scale < 0.5e-8) return;
-    __syncthreads();
   }
   if (j < S::T1) bfly<R1, PS_INV>(x);
   rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);

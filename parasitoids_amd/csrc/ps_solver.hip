@@ -162,7 +162,8 @@ static int set_lds_attr() {
                       (const void*)k_row_inv<false, true>,
                       (const void*)k_col<PS_FWD, false>, (const void*)k_col<PS_FWD, true>,
                       (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>,
-                      (const void*)k_col_fused<false>, (const void*)k_col_fused<true>};
+                      (const void*)k_col_fused<false>, (const void*)k_col_fused<true>,
+                      (const void*)k_row_inv_rs<16, 18, 18, 2>};
   for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   done = true;
   return PS_OK;
@@ -263,8 +264,12 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   ProfScope prof(s, PS_PROF_ROW_INV);
   if (s->row_rs == 1) {
     using S = Rs<16, 18, 18>;
-    const size_t xl = (size_t)(((S::XWORDS + 15) & ~15) + 5 * (S::NTHR / 64)) * sizeof(double);
-    hipLaunchKernelGGL((k_row_inv_rs<16, 18, 18>), dim3(npairs, batch), dim3(S::NTHR), xl, s->stream, a);
+    using Y = RsInvLds<16, 18, 18>;
+    static const int np = getenv("PS_RS_NP") ? atoi(getenv("PS_RS_NP")) : 2;   // row pairs per workgroup
+    if (np == 2)
+      hipLaunchKernelGGL((k_row_inv_rs<16, 18, 18, 2>), dim3((npairs + 1) / 2, batch), dim3(S::NTHR * 2), Y::bytes(2), s->stream, a);
+    else
+      hipLaunchKernelGGL((k_row_inv_rs<16, 18, 18, 1>), dim3(npairs, batch), dim3(S::NTHR), Y::bytes(1), s->stream, a);
   } else if (s->row_plan.generic)
     hipLaunchKernelGGL((k_row_inv<true, false>), grid, dim3(thr), lds, s->stream, a);
   else if (s->row_big)
