@@ -57,6 +57,9 @@ struct ps_solver {
   bool split = false;
   bool row_big = false;  // row plan uses the radix-18/16 butterflies (512-thread workgroups)
   int num_cu = 256;
+  // flag speculation in ps_chain_run: on until this solver has seen a boundary flag
+  bool speculate = true;
+  int spec_window = 1;
   int row_rs = 0;        // register-resident three-stage row kernels (fft_rs.h): 1 = 16*18*18
   int L1 = 0, L2 = 0;
   DevBuf<cplx> tp_lo, tp_hi;
@@ -703,14 +706,55 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
   PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
   s->last_renorm = renorm;
+  s->spec_window = 1;
+  if (getenv("PS_NO_SPECULATION")) s->speculate = false;
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
     PS_TRY(transform_kernels(s, c0, cn));
-    for (int d = c0; d < c0 + cn; ++d) {
+    auto day = [&](int d, bool with_refft) -> int {
       const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
       double* rec = s->recs[PS_REC_CHAIN][d];
       PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale, s->krange.p + 2 * d));
-      PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
+      if (with_refft) PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
+      return PS_OK;
+    };
+    int d = c0;
+    while (d < c0 + cn) {
+      if (!s->speculate) {
+        PS_TRY(day(d, true));
+        ++d;
+        continue;
+      }
+      // Speculation on the boundary flag (CalcSol.py:200-201): a window of days is enqueued
+      // WITHOUT the three flag-conditional re-FFT launches (~6 us each even when they do
+      // nothing), then the window's pad maxima are read back.  No flag: the days stand as
+      // they are (the conditional launches would have returned at once).  First flag at day
+      // f: its truncated field is re-transformed for real, the days after f -- computed from
+      // a spectrum the reference would have replaced -- are redone, and this solver stops
+      // speculating.  Windows grow 1, 2, 4, ... so an early flag wastes almost nothing.
+      const int w = std::min(s->spec_window, c0 + cn - d);
+      for (int i = 0; i < w; ++i) PS_TRY(day(d + i, false));
+      std::vector<unsigned long long> bits((size_t)w);
+      PS_HIP(hipMemcpyAsync(bits.data(), s->padmax.p + d, (size_t)w * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost, s->stream));
+      PS_HIP(hipStreamSynchronize(s->stream));
+      int f = -1;
+      for (int i = 0; i < w && f < 0; ++i) {
+        double m;
+        __builtin_memcpy(&m, &bits[(size_t)i], sizeof(double));
+        if (m > 1e-8) f = d + i;
+      }
+      if (f < 0) {
+        d += w;
+        s->spec_window = std::min(64, 2 * s->spec_window);
+        continue;
+      }
+      PS_TRY(fwd2d(s, s->recs[PS_REC_CHAIN][f], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf),
+                   s->Ahat.p, 1, nullptr));
+      if (d + w - f - 1 > 0)
+        PS_HIP(hipMemsetAsync(s->padmax.p + f + 1, 0, (size_t)(d + w - f - 1) * sizeof(unsigned long long), s->stream));
+      s->speculate = false;
+      d = f + 1;
     }
   }
   return PS_OK;

@@ -177,3 +177,34 @@ def test_error_classes_and_auto_mode(hip_lib):
     a = hip_lib.HipSolve(sparse.coo_matrix(([1.0], ([16], [16])), shape=(33, 33)), [9, 9], mode='auto')
     assert a.mode == 'exact' and a.fft_len == 37               # 37 is prime but <= 1024: planned
     a.close()
+
+
+def test_flag_speculation_is_exact(hip_lib, monkeypatch):
+    '''ps_chain_run enqueues windows of days without the flag-conditional re-FFT launches and
+    checks the pad maxima afterwards; when a flag turns up inside a window the days after it
+    are redone.  The result must be bit-identical to the non-speculative chain, whichever
+    day the first flag falls on.'''
+    from parasitoids_amd import synthetic
+    R, K, nd = 150, 101, 12
+    N = 2 * R + 1
+    for start in (150, 230, 262):          # first flag late / mid-window / early
+        _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(3.0, 6.0), shift=4)
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        runs = []
+        for spec in (True, False):
+            if spec:
+                monkeypatch.delenv('PS_NO_SPECULATION', raising=False)
+            else:
+                monkeypatch.setenv('PS_NO_SPECULATION', '1')
+            s = hip_lib.HipSolve(state, [K, K], mode='exact')
+            s.set_kernels(kernels)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            runs.append(([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st]))
+            s.close()
+        flags = [f for f, _, _, _ in runs[1][1]]
+        assert runs[0][1] == runs[1][1]
+        for a, b in zip(runs[0][0], runs[1][0]):
+            assert np.array_equal(a, b)
+        if start != 150:
+            assert any(flags) and not flags[0]      # the first flag falls inside a later window
