@@ -18,7 +18,7 @@
 #pragma once
 #include "fft_core.h"
 
-#define PS_UNROLL 4
+#define PS_UNROLL 5
 
 // ---------------------------------------------------------------- arguments
 struct SrcMap {  // torus index i -> source index, or -1 (zero)
@@ -290,16 +290,10 @@ __device__ __forceinline__ void col_block(const ColArgs& a, const int bx) {
   cplx* prod = a.prod_dst ? a.prod_dst + (int64_t)blockIdx.y * a.prod_bstride : nullptr;
   cplx* dst = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
   const bool tw_on = a.tw_mode != 0 && o != 0;
-  load_tw(tlo, thi, P);
-  for (int r = threadIdx.x; r < L; r += nthr) {
-    spos[r] = (int)P.pos[r];
-    if (tw_on) stw[r] = tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, o * r);
-  }
-  __syncthreads();
   const int tot = L << a.wsh;
   const int in_base = o * a.in_base_mul, out_base = o * a.out_base_mul;
-  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
-    cplx v[PS_UNROLL], v2[PS_UNROLL];
+  cplx v[PS_UNROLL], v2[PS_UNROLL];
+  auto load_batch = [&](int idx0) {
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
       const int idx = idx0 + u * nthr;
@@ -313,6 +307,8 @@ __device__ __forceinline__ void col_block(const ColArgs& a, const int bx) {
         if (src2) v2[u] = src2[g];
       }
     }
+  };
+  auto store_batch = [&](int idx0) {
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
       const int idx = idx0 + u * nthr;
@@ -327,6 +323,20 @@ __device__ __forceinline__ void col_block(const ColArgs& a, const int bx) {
       const int lrow = DIR == PS_INV ? spos[row] : row;
       data[(lrow << a.wsh) + c] = x;
     }
+  };
+  // the first batch of tile loads is in flight while the tables are fetched: one HBM round
+  // trip for both instead of two
+  load_batch(threadIdx.x);
+  load_tw(tlo, thi, P);
+  for (int r = threadIdx.x; r < L; r += nthr) {
+    spos[r] = (int)P.pos[r];
+    if (tw_on) stw[r] = tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, o * r);
+  }
+  __syncthreads();
+  store_batch(threadIdx.x);
+  for (int idx0 = threadIdx.x + nthr * PS_UNROLL; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+    load_batch(idx0);
+    store_batch(idx0);
   }
   __syncthreads();
   lds_fft<DIR, GEN>(data, tlo, thi, P, PS_MODE_COL, W, a.wsh, 0);
@@ -342,7 +352,7 @@ __device__ __forceinline__ void col_block(const ColArgs& a, const int bx) {
 }
 
 template <int DIR, bool GEN>
-__global__ void k_col(ColArgs a) {
+__global__ void __launch_bounds__(256, 4) k_col(ColArgs a) {
   if (pred_skip(a.pred)) return;
   for (int bx = blockIdx.x; bx < a.nblocks; bx += gridDim.x) {
     col_block<DIR, GEN>(a, bx);
