@@ -36,7 +36,7 @@ ALG_P2 = {
     'refft_pred': 0.0,   # flag-conditional re-FFT launches (40 P^2 per flagged day; no-ops here)
 }
 # kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
-PMC_NAME = {'row_inv': 'void k_row_inv<', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1'}
+PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1'}
 
 
 def pmc_traffic(kernel_class):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collect the judged artefacts of one round on the GPU box: bench line, rocprofv3 kernel
+# stats of the same command, HBM traffic counters (two passes), Bayes bench, parity report,
+# HBM calibration.  usage: scripts/collect_profiles.sh TAG   (from the repo root; writes
+# gpurun_out/TAG_* -- copy into profiles/ afterwards)
+set -e
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p "$out"
+python3 "$root/bench.py" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+python3 "$root/bench_bayes.py" > "$out/${tag}_bench_bayes.json" 2>> "$out/${tag}_bench.err"
+python3 "$root/scripts/hbm_calib.py" > "$out/${tag}_hbm_calibration.txt" 2>&1
+python3 "$root/scripts/parity_report.py" > "$out/${tag}_parity_report.txt" 2>&1 || true
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$out/${tag}_kt" -o kt --output-format csv -- \
+  python3 "$root/bench.py" --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2>> "$out/${tag}_bench.err"
+cp "$out/${tag}_kt"/*kernel_stats.csv "$out/${tag}_bench_kernel_stats.csv"
+BENCH_NO_PROF=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/${tag}_pmc_fetch" -o pmc --output-format csv -- \
+  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> "$out/${tag}_bench.err"
+BENCH_NO_PROF=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/${tag}_pmc_write" -o pmc --output-format csv -- \
+  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> "$out/${tag}_bench.err"
+python3 "$root/scripts/hbm_traffic.py" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" "$out/${tag}_hbm_traffic_pmc.json"
+rm -rf "$out/${tag}_kt" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write"
+echo done
