@@ -49,3 +49,30 @@ def test_bayes_funcs_against_reference(golden, golden_dir):
         np.testing.assert_allclose(card[i], g['card%d' % i], rtol=1e-10, atol=1e-9)
     assert g['grid'].max() > 1.0 and g['sen0'].max() > 1.0     # the fixture is not trivially zero
     pm.close()
+
+
+def test_metropolis_sampler_runs_and_is_reproducible():
+    '''parasitoids_amd.mcmc: priors/likelihood plumbing around PopModel.  Two chains with the
+    same seed give identical traces (the device path is deterministic); the log-posterior is
+    finite; the sampler moves.'''
+    import os
+    import warnings
+    from parasitoids_amd import ParasitoidModel as PM, mcmc
+    from parasitoids_amd.pop_model import PopModel
+    warnings.simplefilter('ignore', RuntimeWarning)
+    root = os.path.dirname(os.path.abspath(__file__))
+    wd, days = PM.get_wind_data(os.path.join(root, 'golden', 'data', 'kalbar'), 30, '00:00')
+    traces = []
+    for rep in range(2):
+        pm = PopModel(wd, days, domain_info=(10000.0, 128), r_number=130000, mode='auto')
+        li = mcmc.synthetic_locinfo(pm, 128, seed=9, ndays=8)
+        assert sum(int(a.sum()) for a in li.release_emerg) > 0 and int(li.grid_obs.sum()) > 0
+        chain = mcmc.Metropolis(pm, li, (10000.0 / 128) ** 2, seed=5, ndays=8)
+        res = chain.run(12)
+        assert np.all(np.isfinite(res['logp']))
+        assert res['evaluations'] >= 12 and 0.0 <= res['acceptance'] <= 1.0
+        traces.append(res['trace'])
+        pm.close()
+    assert np.array_equal(traces[0], traces[1])
+    assert np.ptp(traces[0][:, -3]) > 0            # the nuisance parameters move
+

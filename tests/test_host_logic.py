@@ -106,3 +106,20 @@ def test_params_defaults_and_parsing(tmp_path):
     cfg.write_text('# local configuration\ndataset = carnarvon  # preset\nmu_r = 2.5\nplot = False\n')
     q = Params(config=str(cfg))
     assert q.dataset == 'carnarvon' and q.r_dur == 5 and q.mu_r == 2.5 and q.PLOT is False
+
+
+def test_mcmc_log_densities():
+    '''closed-form checks of the prior/likelihood helpers against scipy.stats'''
+    from scipy import stats
+    from parasitoids_amd import mcmc
+    assert abs(mcmc._lg_gamma(3.1, 26, 0.15) - stats.gamma.logpdf(3.1, 26, scale=1 / 0.15)) < 1e-12
+    assert abs(mcmc._lg_beta(0.3, 5, 1) - stats.beta.logpdf(0.3, 5, 1)) < 1e-12
+    assert abs(mcmc._lg_normal(0.7, 1.0, 1.0) - stats.norm.logpdf(0.7, 1.0, 1.0)) < 1e-12
+    sd = 1 / np.sqrt(0.3)
+    assert abs(mcmc._lg_truncnormal(7.0, 6, 0.3, 0, 9)
+               - stats.truncnorm.logpdf(7.0, (0 - 6) / sd, (9 - 6) / sd, loc=6, scale=sd)) < 1e-12
+    assert mcmc._lg_truncnormal(9.5, 6, 0.3, 0, 9) == float('-inf')
+    assert abs(mcmc._lg_poisson(28, 30) - stats.poisson.logpmf(28, 30)) < 1e-12
+    obs = np.array([[0, 2], [5, 0]]); rate = np.array([[0.0, 1.5], [4.0, 0.2]])
+    assert abs(mcmc.poisson_loglik(obs, rate) - stats.poisson.logpmf(obs, rate)[rate > 0].sum()) < 1e-12
+    assert mcmc.poisson_loglik(np.array([1]), np.array([0.0])) == float('-inf')
