@@ -123,6 +123,12 @@ int ps_record_stats(ps_solver* s, int kind, int idx, double negval, double stat_
 int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negval, double stat_scale,
                         double delta, double post_scale, int32_t* row, int32_t* col,
                         double* val, int64_t cap, int64_t* nnz_out);
+/* The same entries as CSR triplets (indptr[N+1], indices, data): what `.tocsr()` of the COO
+ * result holds and what the reference's result files store per day (Run.py:490-516,
+ * read back by Plot_Result.py:511-524) -- straight from the device compaction, no host sort. */
+int ps_record_fetch_csr(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                        double delta, double post_scale, int32_t* indptr /* N+1 */,
+                        int32_t* indices, double* data, int64_t cap, int64_t* nnz_out);
 int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out /* N*N */);
 /* Point gather from a record: out[i] = v*scale at (rows[i], cols[i]), 0 where v*scale < negval
  * -- what indexing the thresholded daily CSR solutions returns in Bayes_funcs.popdensity_grid /

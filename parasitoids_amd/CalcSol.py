@@ -154,7 +154,7 @@ def get_populations(r_spread, pmf_list, days, ndays, dom_len, max_shape,
     try:
         # first day: r_small_vals(r_spread[0]) * r_number * dist(1), rest still at the origin
         st = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
-        first = solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, r_number * dist(1), st.nnz).tocsr()
+        first = solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, r_number * dist(1), st.nnz, 'csr')
         first[mid, mid] += r_number * (1 - dist(1))
         popmodel.append(first)
 
@@ -167,14 +167,14 @@ def get_populations(r_spread, pmf_list, days, ndays, dom_len, max_shape,
                 stats = solver.chain_stats(0, nk)
                 for n in range(nk):
                     popmodel.append(solver._fetch(L.REC_CHAIN, n, 1e-8, scale, 0.0, 1.0,
-                                                  stats[n].nnz).tocsr())
+                                                  stats[n].nnz, 'csr'))
             return popmodel
 
         def weighted(kinds, idxs, ndist):
             w = [dist(d + 1) * r_number for d in range(ndist)]
             solver.weighted_sum(kinds, idxs, w)
             stw = solver.record_stats(L.REC_WSUM, 0, 1e-8, 1.0, False)
-            return solver._fetch(L.REC_WSUM, 0, 1e-8, 1.0, 0.0, 1.0, stw.nnz).tocsr()
+            return solver._fetch(L.REC_WSUM, 0, 1e-8, 1.0, 0.0, 1.0, stw.nnz, 'csr')
 
         # successive release days (CalcSol.py:296-306)
         for day in range(1, r_dur):

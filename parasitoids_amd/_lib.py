@@ -69,6 +69,8 @@ SIGNATURES = {
                                   C.POINTER(DayStats)]),
     'ps_record_fetch_coo': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                       C.c_double, _I32P, _I32P, _F64P, C.c_int64, _I64P]),
+    'ps_record_fetch_csr': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, _I32P, _I32P, _F64P, C.c_int64, _I64P]),
     'ps_record_fetch_dense': (C.c_int, [_VP, C.c_int, C.c_int, _F64P]),
     'ps_record_gather': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int64, _I32P, _I32P, C.c_double,
                                    C.c_double, _F64P]),

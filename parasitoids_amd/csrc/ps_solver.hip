@@ -879,9 +879,10 @@ extern "C" int ps_record_stats(ps_solver* s, int kind, int idx, double negval, d
   return PS_OK;
 }
 
-extern "C" int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negval, double stat_scale,
-                                   double delta, double post_scale, int32_t* row, int32_t* col,
-                                   double* val, int64_t cap, int64_t* nnz_out) {
+// shared body of the COO and CSR fetches: statistics, row offsets, ordered compaction
+static int fetch_sparse(ps_solver* s, int kind, int idx, double negval, double stat_scale, double delta,
+                        double post_scale, int32_t* row, int32_t* indptr, int32_t* col, double* val,
+                        int64_t cap, int64_t* nnz_out) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
   PS_HIP(hipSetDevice(s->device));
   double* rec;
@@ -900,8 +901,15 @@ extern "C" int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negva
   PS_HIP(hipMemcpy(&last_cnt, rc + (s->N - 1), sizeof(long long), hipMemcpyDeviceToHost));
   const int64_t nnz = last_off + last_cnt;
   if (nnz_out) *nnz_out = nnz;
-  if (!row || !col || !val) return PS_OK;  // count only
-  if (cap < nnz) return ps_fail(PS_ERR_BAD_ARG, "fetch_coo: capacity %lld < nnz %lld", (long long)cap, (long long)nnz);
+  if ((!row && !indptr) || !col || !val) return PS_OK;  // count only
+  if (cap < nnz) return ps_fail(PS_ERR_BAD_ARG, "fetch: capacity %lld < nnz %lld", (long long)cap, (long long)nnz);
+  if (indptr) {
+    if (nnz > 0x7fffffffLL) return ps_fail(PS_ERR_UNSUPPORTED, "fetch_csr: %lld entries do not fit int32 offsets", (long long)nnz);
+    std::vector<long long> off((size_t)s->N);
+    PS_HIP(hipMemcpy(off.data(), s->rowoff.p, (size_t)s->N * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < s->N; ++i) indptr[i] = (int32_t)off[(size_t)i];
+    indptr[s->N] = (int32_t)nnz;
+  }
   if (nnz == 0) return PS_OK;
   PS_TRY(s->orow.ensure(nnz));
   PS_TRY(s->ocol.ensure(nnz));
@@ -911,11 +919,23 @@ extern "C" int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negva
   hipLaunchKernelGGL(k_compact_rows, dim3(blocks), dim3(thr), 0, s->stream, rec, s->N, stat_scale, negval,
                      delta, post_scale, s->rowoff.p, s->orow.p, s->ocol.p, s->oval.p);
   PS_HIP(hipGetLastError());
-  PS_HIP(hipMemcpyAsync(row, s->orow.p, nnz * 4, hipMemcpyDeviceToHost, s->stream));
+  if (row) PS_HIP(hipMemcpyAsync(row, s->orow.p, nnz * 4, hipMemcpyDeviceToHost, s->stream));
   PS_HIP(hipMemcpyAsync(col, s->ocol.p, nnz * 4, hipMemcpyDeviceToHost, s->stream));
   PS_HIP(hipMemcpyAsync(val, s->oval.p, nnz * 8, hipMemcpyDeviceToHost, s->stream));
   PS_HIP(hipStreamSynchronize(s->stream));
   return PS_OK;
+}
+
+extern "C" int ps_record_fetch_coo(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                                   double delta, double post_scale, int32_t* row, int32_t* col,
+                                   double* val, int64_t cap, int64_t* nnz_out) {
+  return fetch_sparse(s, kind, idx, negval, stat_scale, delta, post_scale, row, nullptr, col, val, cap, nnz_out);
+}
+
+extern "C" int ps_record_fetch_csr(ps_solver* s, int kind, int idx, double negval, double stat_scale,
+                                   double delta, double post_scale, int32_t* indptr, int32_t* indices,
+                                   double* data, int64_t cap, int64_t* nnz_out) {
+  return fetch_sparse(s, kind, idx, negval, stat_scale, delta, post_scale, nullptr, indptr, indices, data, cap, nnz_out);
 }
 
 extern "C" int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out) {

@@ -203,9 +203,9 @@ class HipSolve():
         L.check(self._lib.ps_chain_stats(self._h, first, count, stats))
         return list(stats)
 
-    def chain_solution(self, day, stats, negval=1e-8, scale=1.0):
-        '''r_small_vals(A, prob_model=renorm) of chain day `day` as a coo matrix.'''
-        return self._fetch(L.REC_CHAIN, day, negval, scale, stats.delta, 1.0, stats.nnz)
+    def chain_solution(self, day, stats, negval=1e-8, scale=1.0, fmt='coo'):
+        '''r_small_vals(A, prob_model=renorm) of chain day `day` as a coo (or csr) matrix.'''
+        return self._fetch(L.REC_CHAIN, day, negval, scale, stats.delta, 1.0, stats.nnz, fmt)
 
     def record_stats(self, kind, idx, negval=1e-8, scale=1.0, renorm=False):
         st = L.DayStats()
@@ -267,21 +267,26 @@ class HipSolve():
             raise ValueError('dom_shape {} != solver domain {}'.format(
                 tuple(dom_shape), self.dom_len))
 
-    def _fetch(self, kind, idx, negval, scale, delta, post, nnz_hint):
+    def _fetch(self, kind, idx, negval, scale, delta, post, nnz_hint, fmt='coo'):
+        """Thresholded record as a scipy sparse matrix.  fmt='coo': row-major COO (what
+        `coo_matrix(dense)` gives, CalcSol.py:41); fmt='csr': the CSR triplets straight from the
+        device compaction (what `.tocsr()` / the reference's result files hold)."""
         n = int(nnz_hint)
         cap = max(n, 1)
+        N = self.dom_len
         while True:
-            row = np.empty(cap, dtype=np.int32)
+            first = np.empty(cap if fmt == 'coo' else N + 1, dtype=np.int32)
             col = np.empty(cap, dtype=np.int32)
             val = np.empty(cap, dtype=np.float64)
             nnz = C.c_int64()
-            rc = self._lib.ps_record_fetch_coo(self._h, kind, idx, negval, scale, delta, post,
-                                               L.p_i32(row), L.p_i32(col), L.p_f64(val), cap,
-                                               C.byref(nnz))
+            fn = self._lib.ps_record_fetch_coo if fmt == 'coo' else self._lib.ps_record_fetch_csr
+            rc = fn(self._h, kind, idx, negval, scale, delta, post, L.p_i32(first), L.p_i32(col),
+                    L.p_f64(val), cap, C.byref(nnz))
             if rc == L.PS_ERR_BAD_ARG and nnz.value > cap:
                 cap = nnz.value
                 continue
             L.check(rc)
             n = nnz.value
-            return sparse.coo_matrix((val[:n], (row[:n], col[:n])),
-                                     shape=(self.dom_len, self.dom_len))
+            if fmt == 'coo':
+                return sparse.coo_matrix((val[:n], (first[:n], col[:n])), shape=(N, N))
+            return sparse.csr_matrix((val[:n], col[:n], first), shape=(N, N))

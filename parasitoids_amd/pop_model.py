@@ -84,9 +84,9 @@ class PopModel():
         scale = float(self.r_number)
         if day == 0:
             st = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
-            return solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, scale, st.nnz).tocsr()
+            return solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, scale, st.nnz, 'csr')
         st = self.stats[day - 1]
-        return solver._fetch(L.REC_CHAIN, day - 1, 1e-8, scale, st.delta, 1.0, st.nnz).tocsr()
+        return solver._fetch(L.REC_CHAIN, day - 1, 1e-8, scale, st.delta, 1.0, st.nnz, 'csr')
 
     def moments(self, day):
         '''(total, mean_row, mean_col, var_row, var_col) of one day's raw field, in cells.'''

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 from scipy import sparse, signal, fft as sfft
 
-from helpers import coo_from, assert_summary
+from helpers import coo_from, assert_summary, recentre
 
 pytestmark = pytest.mark.gpu
 
@@ -153,3 +153,27 @@ def test_save_result_format(golden_dir, tmp_path):
     q = Run.Params(config=None)
     q.file_read_chg(p.outfile)
     assert tuple(q.domain_info) == (10000.0, 64) and q.ndays == 2
+
+
+def test_fetch_csr_equals_coo_tocsr(golden):
+    '''ps_record_fetch_csr: the CSR triplets from the device compaction are exactly what
+    scipy builds from the COO result (the format of the reference's result files,
+    Run.py:490-516), including empty rows and an all-zero record.'''
+    from parasitoids_amd import hip_lib, _lib as L
+    g = golden('g6_solutions')
+    nd = 4
+    pmfs = [coo_from(g, 'r128_pmf%d' % i) for i in range(nd)]
+    s = hip_lib.HipSolve(recentre(pmfs[0], 128), g['r128_max_shape'])
+    s.set_kernels(pmfs[1:])
+    s.run_chain(renorm=True)
+    st = s.chain_stats(0, nd - 1)
+    for d in range(nd - 1):
+        a = s.chain_solution(d, st[d]).tocsr()
+        b = s.chain_solution(d, st[d], fmt='csr')
+        assert b.format == 'csr' and b.has_sorted_indices
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+        assert np.array_equal(a.data, b.data)
+    # threshold above every value: empty matrix, indptr all zero
+    e = s._fetch(L.REC_CHAIN, 0, 10.0, 1.0, 0.0, 1.0, 0, 'csr')
+    assert e.nnz == 0 and e.shape == (257, 257) and not e.indptr.any()
+    s.close()
