@@ -14,6 +14,20 @@ static __global__ void k_scatter_coo(const int* __restrict__ row, const int* __r
     atomicAdd(&dst[(int64_t)(row[i] + roff) * ld + col[i] + coff], val[i]);
 }
 
+// batched form: day d = blockIdx.y scatters its triplets [koff[d], koff[d+1]) into the d-th
+// K x K staging block, centred (offset M - kshape[d]/2): one launch per chunk of kernels
+static __global__ void k_scatter_coo_batch(const int* __restrict__ row, const int* __restrict__ col,
+                                           const double* __restrict__ val, const long long* __restrict__ koff,
+                                           const int* __restrict__ kshape, int first, double* dst, int K) {
+  const int d = first + blockIdx.y;
+  const long long lo = koff[d], hi = koff[d + 1];
+  const int off = K / 2 - kshape[d] / 2;
+  double* out = dst + (int64_t)blockIdx.y * K * K;
+  for (long long i = lo + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < hi;
+       i += (long long)gridDim.x * blockDim.x)
+    atomicAdd(&out[(int64_t)(row[i] + off) * K + col[i] + off], val[i]);
+}
+
 struct DayStats {
   long long nnz;      // entries with v*scale >= negval
   double sum;         // their sum

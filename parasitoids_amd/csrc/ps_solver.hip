@@ -76,6 +76,8 @@ struct ps_solver {
   int nk = 0, Kmax = 0;
   bool kernels_on_device = false;
   DevBuf<double> kdense;
+  DevBuf<long long> dkoff;   // device copies of koff / kshape for the batched scatter
+  DevBuf<int> dkshape;
   int bhat_first = -1, bhat_count = 0;  // which days' transforms Bhat currently holds
   // records
   std::vector<double*> recs[4];
@@ -600,12 +602,29 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   PS_TRY(s->kdense.ensure((size_t)count * K * K));
   PS_TRY(s->Bhat.ensure(spec * count));
   PS_TRY(ensure_temps(s, count));
-  PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)count * K * K * sizeof(double), s->stream));
-  for (int d = 0; d < count; ++d) {
-    const int64_t o = s->koff[first + d], n = s->koff[first + d + 1] - o;
-    const int off = M - s->kshape[first + d] / 2;
-    PS_TRY(scatter_from_device(s, s->krow.p + o, s->kcol.p + o, s->kval.p + o, n,
-                               s->kdense.p + (size_t)d * K * K, K, off));
+  // zero only the band of staging rows some kernel of the chunk writes (the row pass reads
+  // nothing else, see krange), in one strided memset; then one batched scatter launch
+  int blo = K, bhi = -1;
+  int64_t maxn = 0;
+  for (int d = first; d < first + count; ++d) {
+    if (s->hkrange[2 * d] <= s->hkrange[2 * d + 1]) {
+      blo = std::min(blo, s->hkrange[2 * d]);
+      bhi = std::max(bhi, s->hkrange[2 * d + 1]);
+    }
+    maxn = std::max<int64_t>(maxn, s->koff[d + 1] - s->koff[d]);
+  }
+  if (bhi >= blo) {
+    blo = std::max(blo, 0);
+    bhi = std::min(bhi, K - 1);
+    PS_HIP(hipMemset2DAsync(s->kdense.p + (size_t)blo * K, (size_t)K * K * sizeof(double), 0,
+                            (size_t)(bhi - blo + 1) * K * sizeof(double), (size_t)count, s->stream));
+  }
+  if (maxn > 0) {
+    const int thr = 256;
+    const int blocks = (int)std::min<int64_t>((maxn + thr - 1) / thr, 1024);
+    hipLaunchKernelGGL(k_scatter_coo_batch, dim3(blocks, count), dim3(thr), 0, s->stream, s->krow.p, s->kcol.p,
+                       s->kval.p, s->dkoff.p, s->dkshape.p, first, s->kdense.p, K);
+    PS_HIP(hipGetLastError());
   }
   PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count,
                        s->krange.p + 2 * first));
@@ -651,6 +670,13 @@ static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const in
     s->hkrange[2 * d + 1] = hi + o;
   }
   PS_TRY(s->krange.ensure(s->hkrange.size()));
+  PS_TRY(s->dkoff.ensure((size_t)nk + 1));
+  PS_TRY(s->dkshape.ensure((size_t)std::max(nk, 1)));
+  {
+    std::vector<long long> o64(off, off + nk + 1);
+    PS_HIP(hipMemcpy(s->dkoff.p, o64.data(), o64.size() * sizeof(long long), hipMemcpyHostToDevice));
+    if (nk > 0) PS_HIP(hipMemcpy(s->dkshape.p, kshape, (size_t)nk * sizeof(int), hipMemcpyHostToDevice));
+  }
   PS_HIP(hipMemcpyAsync(s->krange.p, s->hkrange.data(), s->hkrange.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
   PS_HIP(hipStreamSynchronize(s->stream));
   s->bhat_first = -1;
