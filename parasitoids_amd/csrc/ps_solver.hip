@@ -1,6 +1,8 @@
 // libparasitoid_hip.so -- day-chain FFT convolution solver (C ABI in
 // include/parasitoid_hip.h).  Replaces cuda_lib.CudaSolve (cuda_lib.py:16-221) and
 // the CPU chain of CalcSol.py:140-325 with fp64 HIP kernels for gfx950.
+#include <deque>
+
 #include "chain_kernels.h"
 #include "fft_kernels.h"
 #include "fft_rs_kernels.h"
@@ -60,6 +62,9 @@ struct ps_solver {
   // flag speculation in ps_chain_run: on until this solver has seen a boundary flag
   bool speculate = true;
   int spec_window = 1;
+  hipEvent_t spec_ev[2] = {nullptr, nullptr};
+  unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
+  int hflags_n = 0;
   int row_rs = 0;        // register-resident three-stage row kernels (fft_rs.h): 1 = 16*18*18
   int L1 = 0, L2 = 0;
   DevBuf<cplx> tp_lo, tp_hi;
@@ -516,6 +521,9 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   s->orow.release(); s->ocol.release(); s->oval.release(); s->wptr.release(); s->wval.release();
   for (auto& r : s->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : s->prof_pool) (void)hipEventDestroy(e);
+  for (auto e : s->spec_ev) if (e) (void)hipEventDestroy(e);
+  if (s->hflags) (void)hipHostFree(s->hflags);
+  s->dkoff.release(); s->dkshape.release();
   delete s;
   return PS_OK;
 }
@@ -734,6 +742,17 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   s->last_renorm = renorm;
   s->spec_window = 1;
   if (getenv("PS_NO_SPECULATION")) s->speculate = false;
+  if (s->speculate) {
+    for (int i = 0; i < 2; ++i)
+      if (!s->spec_ev[i]) PS_HIP(hipEventCreateWithFlags(&s->spec_ev[i], hipEventDisableTiming));
+    if (s->hflags_n < first + count) {
+      if (s->hflags) (void)hipHostFree(s->hflags);
+      s->hflags = nullptr;
+      s->hflags_n = 0;
+      PS_HIP(hipHostMalloc((void**)&s->hflags, (size_t)(first + count) * sizeof(unsigned long long), hipHostMallocDefault));
+      s->hflags_n = first + count;
+    }
+  }
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
     PS_TRY(transform_kernels(s, c0, cn));
@@ -744,41 +763,51 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       if (with_refft) PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
       return PS_OK;
     };
-    int d = c0;
-    while (d < c0 + cn) {
+    // Speculation on the boundary flag (CalcSol.py:200-201): windows of days are enqueued
+    // WITHOUT the three flag-conditional re-FFT launches (~6 us each even when they do
+    // nothing) and their pad maxima are copied to pinned host memory behind them.  The host
+    // checks a window only after the NEXT one has been enqueued, so the GPU never waits for
+    // the check.  No flag: the days stand as they are (the conditional launches would have
+    // returned at once).  First flag at day f: its truncated field is re-transformed for
+    // real, every day after f -- computed from a spectrum the reference would have replaced
+    // -- is redone, and this solver stops speculating.  Windows grow 1, 2, 4, ... so an
+    // early flag wastes little.
+    struct Win { int d0, w, ev; };
+    std::deque<Win> q;
+    int d = c0, nev = 0;
+    while (true) {
       if (!s->speculate) {
-        PS_TRY(day(d, true));
-        ++d;
-        continue;
+        for (; d < c0 + cn; ++d) PS_TRY(day(d, true));
+        break;
       }
-      // Speculation on the boundary flag (CalcSol.py:200-201): a window of days is enqueued
-      // WITHOUT the three flag-conditional re-FFT launches (~6 us each even when they do
-      // nothing), then the window's pad maxima are read back.  No flag: the days stand as
-      // they are (the conditional launches would have returned at once).  First flag at day
-      // f: its truncated field is re-transformed for real, the days after f -- computed from
-      // a spectrum the reference would have replaced -- are redone, and this solver stops
-      // speculating.  Windows grow 1, 2, 4, ... so an early flag wastes almost nothing.
-      const int w = std::min(s->spec_window, c0 + cn - d);
-      for (int i = 0; i < w; ++i) PS_TRY(day(d + i, false));
-      std::vector<unsigned long long> bits((size_t)w);
-      PS_HIP(hipMemcpyAsync(bits.data(), s->padmax.p + d, (size_t)w * sizeof(unsigned long long),
-                            hipMemcpyDeviceToHost, s->stream));
-      PS_HIP(hipStreamSynchronize(s->stream));
-      int f = -1;
-      for (int i = 0; i < w && f < 0; ++i) {
-        double m;
-        __builtin_memcpy(&m, &bits[(size_t)i], sizeof(double));
-        if (m > 1e-8) f = d + i;
-      }
-      if (f < 0) {
+      static const size_t depth = getenv("PS_SPEC_DEPTH") ? (size_t)atoi(getenv("PS_SPEC_DEPTH")) : 2;
+      while (q.size() < depth && d < c0 + cn) {
+        const int w = std::min(s->spec_window, c0 + cn - d);
+        for (int i = 0; i < w; ++i) PS_TRY(day(d + i, false));
+        PS_HIP(hipMemcpyAsync(s->hflags + d, s->padmax.p + d, (size_t)w * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, s->stream));
+        PS_HIP(hipEventRecord(s->spec_ev[nev & 1], s->stream));
+        q.push_back(Win{d, w, nev & 1});
+        ++nev;
         d += w;
         s->spec_window = std::min(64, 2 * s->spec_window);
-        continue;
       }
+      if (q.empty()) break;
+      const Win x = q.front();
+      q.pop_front();
+      PS_HIP(hipEventSynchronize(s->spec_ev[x.ev]));
+      int f = -1;
+      for (int i = 0; i < x.w && f < 0; ++i) {
+        double m;
+        __builtin_memcpy(&m, &s->hflags[x.d0 + i], sizeof(double));
+        if (m > 1e-8) f = x.d0 + i;
+      }
+      if (f < 0) continue;
+      q.clear();   // whatever was enqueued after day f is void; stream order keeps it harmless
       PS_TRY(fwd2d(s, s->recs[PS_REC_CHAIN][f], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf),
                    s->Ahat.p, 1, nullptr));
-      if (d + w - f - 1 > 0)
-        PS_HIP(hipMemsetAsync(s->padmax.p + f + 1, 0, (size_t)(d + w - f - 1) * sizeof(unsigned long long), s->stream));
+      if (d - f - 1 > 0)
+        PS_HIP(hipMemsetAsync(s->padmax.p + f + 1, 0, (size_t)(d - f - 1) * sizeof(unsigned long long), s->stream));
       s->speculate = false;
       d = f + 1;
     }
