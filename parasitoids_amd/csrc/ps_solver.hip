@@ -345,7 +345,10 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   a.live = s->kt_live;
   a.live.range = rowrange;
   a.prog = plan->prog;
-  a.wsh = col_wsh(a.prog.L);
+  // 16-column tiles: the fused pass keeps four tile transfers in flight per workgroup, and
+  // twice as many (smaller) workgroups per CU beat the 512-byte segments of W = 32 (+1.7 %)
+  a.wsh = std::min(col_wsh(a.prog.L), 4);
+  if (const char* e = getenv("PS_FUSED_WSH")) a.wsh = atoi(e);   // tuning knob
   auto need = [&](int wsh) {
     return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
   };
