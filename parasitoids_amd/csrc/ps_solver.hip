@@ -357,10 +357,11 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   const int W = 1 << a.wsh;
   dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
   ProfScope prof(s, PS_PROF_COL_INV_A);
+  static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
   if (plan->generic)
-    hipLaunchKernelGGL(k_col_fused<true>, grid, dim3(col_threads()), need(a.wsh), s->stream, a);
+    hipLaunchKernelGGL(k_col_fused<true>, grid, dim3(fthr), need(a.wsh), s->stream, a);
   else
-    hipLaunchKernelGGL(k_col_fused<false>, grid, dim3(col_threads()), need(a.wsh), s->stream, a);
+    hipLaunchKernelGGL(k_col_fused<false>, grid, dim3(fthr), need(a.wsh), s->stream, a);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }

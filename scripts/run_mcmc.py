@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """MCMC samples/hour with the in-repo Metropolis sampler (parasitoids_amd/mcmc.py): Kalbar
-wind (the reference's data file), the reference's priors and Poisson observation model, one
-chain on one GPU.  The OBSERVATIONS ARE SYNTHETIC -- drawn from the model at the reference's
-initial parameter values on a Kalbar-like sampling geometry -- because the xlsx field data
-cannot be read in this image; the cost per sample does not depend on that.
+wind and Kalbar field observations (the reference's data files; the xlsx sheets as CSV
+fixtures, parasitoids_amd/Data_Import.py), the reference's priors and Poisson observation
+model, one chain on one GPU.  --synthetic draws the observations from the model itself on a
+Kalbar-like geometry instead.
 
-    python scripts/run_mcmc.py [--samples 200] [--rad-res 400] [--mode auto] [--seed 1000]
+    python scripts/run_mcmc.py [--samples 200] [--rad-res 400] [--mode auto] [--seed 1000] [--synthetic]
 """
 import argparse
 import json
@@ -26,6 +26,9 @@ def main():
     ap.add_argument('--rad-res', type=int, default=400)
     ap.add_argument('--mode', default='auto', choices=['exact', 'fast', 'auto'])
     ap.add_argument('--seed', type=int, default=1000)
+    ap.add_argument('--synthetic', action='store_true',
+                    help='observations drawn from the model on a Kalbar-like geometry instead of '
+                         'the Kalbar field data (tests/golden/data CSV fixtures)')
     args = ap.parse_args()
     warnings.simplefilter('ignore', RuntimeWarning)
     from parasitoids_amd import ParasitoidModel as PM
@@ -33,13 +36,17 @@ def main():
     from parasitoids_amd.pop_model import PopModel
     wd, days = PM.get_wind_data(os.path.join(ROOT, 'tests', 'golden', 'data', 'kalbar'), 30, '00:00')
     pm = PopModel(wd, days, domain_info=(10000.0, args.rad_res), r_number=130000, mode=args.mode)
-    li = mcmc.synthetic_locinfo(pm, args.rad_res, seed=9)
+    if args.synthetic:
+        li = mcmc.synthetic_locinfo(pm, args.rad_res, seed=9)
+    else:
+        from parasitoids_amd.Data_Import import LocInfo
+        li = LocInfo('kalbar', (-27.947131, 152.584171), (10000.0, args.rad_res))   # Run.py:129
     cell_area = (10000.0 / args.rad_res) ** 2
     chain = mcmc.Metropolis(pm, li, cell_area, seed=args.seed)
     chain.run(args.burn)
     res = chain.run(args.samples)
     tr = res['trace']
-    out = {'metric': 'MCMC samples/hour (Kalbar wind, synthetic observations)',
+    out = {'metric': 'MCMC samples/hour (Kalbar wind, %s observations)' % ('synthetic' if args.synthetic else 'Kalbar field'),
            'value': round(res['samples_per_hour'], 1), 'unit': 'samples/hour', 'n_gpus': 1,
            'samples': args.samples, 'ms_per_sample': round(1e3 * res['seconds'] / args.samples, 3),
            'acceptance': round(res['acceptance'], 3),

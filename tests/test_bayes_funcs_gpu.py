@@ -76,3 +76,30 @@ def test_metropolis_sampler_runs_and_is_reproducible():
     assert np.array_equal(traces[0], traces[1])
     assert np.ptp(traces[0][:, -3]) > 0            # the nuisance parameters move
 
+
+
+def test_metropolis_on_kalbar_field_data():
+    '''the sampler on the real Kalbar observations (Data_Import.LocInfo on the CSV fixtures):
+    finite log-posterior, deterministic, expected observations shaped like the data'''
+    import os
+    import warnings
+    from parasitoids_amd import ParasitoidModel as PM, mcmc
+    from parasitoids_amd.Data_Import import LocInfo
+    from parasitoids_amd.pop_model import PopModel
+    warnings.simplefilter('ignore', RuntimeWarning)
+    root = os.path.dirname(os.path.abspath(__file__))
+    wd, days = PM.get_wind_data(os.path.join(root, 'golden', 'data', 'kalbar'), 30, '00:00')
+    R = 200
+    li = LocInfo('kalbar', (-27.947131, 152.584171), (10000.0, R))
+    logps = []
+    for rep in range(2):
+        pm = PopModel(wd, days, domain_info=(10000.0, R), r_number=130000, mode='auto')
+        chain = mcmc.Metropolis(pm, li, (10000.0 / R) ** 2, seed=3)
+        rel, sen, grid = chain.expected
+        assert rel[0].shape == li.release_emerg[0].shape and sen[0].shape == li.sentinel_emerg[0].shape
+        assert grid.shape == li.grid_obs.shape and grid.sum() > 0
+        res = chain.run(6)
+        assert np.all(np.isfinite(res['logp']))
+        logps.append(res['logp'])
+        pm.close()
+    assert np.array_equal(logps[0], logps[1])

@@ -123,3 +123,62 @@ def test_mcmc_log_densities():
     obs = np.array([[0, 2], [5, 0]]); rate = np.array([[0.0, 1.5], [4.0, 0.2]])
     assert abs(mcmc.poisson_loglik(obs, rate) - stats.poisson.logpmf(obs, rate)[rate > 0].sum()) < 1e-12
     assert mcmc.poisson_loglik(np.array([1]), np.array([0.0])) == float('-inf')
+
+
+def test_locinfo_loader_kalbar():
+    """parasitoids_amd.Data_Import.LocInfo on the CSV/text fixtures of the Kalbar campaign:
+    no golden exists (the reference's loader cannot run in this image), so the arrays are
+    checked against direct reductions of the fixture files and against the geometry."""
+    import csv
+    import pandas as pd
+    from parasitoids_amd.Data_Import import LocInfo, latlong_tocoord, DEFAULT_DATA_DIR
+    R = 400
+    li = LocInfo('kalbar', (-27.947131, 152.584171), (10000.0, R))
+    N = 2 * R + 1
+
+    def rows(name):
+        with open(os.path.join(DEFAULT_DATA_DIR, name)) as f:
+            return list(csv.DictReader(f))
+
+    # fields: A is the release field, B..G the sentinels; every cell inside the domain
+    assert sorted(li.field_cells) == list('ABCDEFG') and li.sent_ids == list('BCDEFG')
+    for k, c in li.field_cells.items():
+        assert c.ndim == 2 and c.shape[1] == 2 and c.min() >= 0 and c.max() < N
+        assert li.field_sizes[k] == len(c) > 10
+        # cell centres of a field lie inside the bounding box of its polygon
+        xy = np.array(li.field_polys[k])
+        x = (c[:, 1] - R) * 25.0
+        y = (R - c[:, 0]) * 25.0
+        assert x.min() >= xy[:, 0].min() - 1e-9 and x.max() <= xy[:, 0].max() + 1e-9
+        assert y.min() >= xy[:, 1].min() - 1e-9 and y.max() <= xy[:, 1].max() + 1e-9
+    # the release point is inside field A
+    assert any((c == [R, R]).all() for c in li.field_cells['A'])
+    assert abs(latlong_tocoord((0, 0), 0.0, 1.0)[0] - 6378100 * np.pi / 180) < 1e-6
+    # release grid: one cell per line of the text file, rotation keeps the distance to the origin
+    assert li.grid_cells.shape == (75, 2) and li.grid_cells.min() >= 0 and li.grid_cells.max() < N
+    d = np.hypot(li.grid_data['xcoord'], li.grid_data['ycoord'])
+    assert 0 < d.max() < 500 and li.grid_samples.max() == 1.0 and li.grid_samples.min() > 0
+    # sentinel emergence: E = females + males, every row of the sheet lands in the array
+    sen = rows('kalbar_sentinels_raw.csv')
+    assert li.sentinel_emerg[0].shape == (6, 10)
+    assert li.sentinel_emerg[0].sum() == sum(int(r['Efemales']) + int(r['Emales']) for r in sen)
+    by_field = {k: sum(int(r['Efemales']) + int(r['Emales']) for r in sen if r['Field ID (jpgs)'] == k)
+                for k in li.sent_ids}
+    assert [by_field[k] for k in li.sent_ids] == li.sentinel_emerg[0].sum(axis=1).tolist()
+    assert li.collection_datesPR[0].days == 18
+    # release-field emergence: points on the two axes through the release point are dropped
+    rel = [r for r in rows('kalbar_releasefield_raw.csv')
+           if float(r['ycoord']) - 200 != 0 and -float(r['xcoord']) + 300 != 0]
+    assert li.release_emerg[0].sum() == sum(int(r['Efemales']) + int(r['Emales']) for r in rel)
+    assert li.release_emerg[0].shape == (len(li.emerg_grids[0]), 10) == (15, 10)
+    grid = {tuple(c) for c in li.grid_cells.tolist()}
+    assert all(tuple(int(v) for v in g) in grid for g in li.emerg_grids[0])
+    assert li.release_collection[0].max() == 1.0 and li.release_collection[0].min() > 0
+    # grid counts: every non-zero observation of the sheet is found on a grid point
+    obs = rows('kalbar_adult_counts_field_A.csv')
+    assert li.grid_obs.shape == (75, 3) and [t.days for t in li.grid_obs_datesPR] == [2, 5, 8]
+    assert li.grid_obs.sum() == sum(int(r['num hayati']) for r in obs)
+    # cardinal directions
+    assert [a.shape[0] for a in li.card_obs] == [4, 4] and [t.days for t in li.card_obs_datesPR] == [2, 8]
+    for a, name in zip(li.card_obs, ('kalbar_cardinal_15mar05.csv', 'kalbar_cardinal_21mar05.csv')):
+        assert a.sum() == sum(int(r['num adults']) for r in rows(name))
