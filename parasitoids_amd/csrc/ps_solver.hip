@@ -65,7 +65,7 @@ struct ps_solver {
   hipEvent_t spec_ev[2] = {nullptr, nullptr};
   unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
   int hflags_n = 0;
-  int row_rs = 0;        // register-resident three-stage row kernels (fft_rs.h): 1 = 16*18*18
+  int row_rs = 0;        // register-resident three-stage row kernels (fft_rs.h): 1 = 16*18*18, 2 = 16*18*9, 3 = 16*9*9
   int L1 = 0, L2 = 0;
   DevBuf<cplx> tp_lo, tp_hi;
   int tp_shift = 0;
@@ -272,14 +272,17 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, PS_PROF_ROW_INV);
-  if (s->row_rs == 1) {
-    using S = Rs<16, 18, 18>;
-    using Y = RsInvLds<16, 18, 18>;
-    static const int np = getenv("PS_RS_NP") ? atoi(getenv("PS_RS_NP")) : 2;   // row pairs per workgroup
-    if (np == 2)
-      hipLaunchKernelGGL((k_row_inv_rs<16, 18, 18, 2>), dim3((npairs + 1) / 2, batch), dim3(S::NTHR * 2), Y::bytes(2), s->stream, a);
-    else
-      hipLaunchKernelGGL((k_row_inv_rs<16, 18, 18, 1>), dim3(npairs, batch), dim3(S::NTHR), Y::bytes(1), s->stream, a);
+  if (s->row_rs != 0) {
+    // register-resident kernels for the sizes of the nominal family P' = 81 * 2^m
+    // (R = 2^k, K = R + 1): 5184 = 16*18*18, 2592 = 16*18*9, 1296 = 16*9*9
+    auto go = [&](auto kern, int nthr, int np, size_t lds_bytes) {
+      hipLaunchKernelGGL(kern, dim3((npairs + np - 1) / np, batch), dim3(nthr * np), lds_bytes, s->stream, a);
+    };
+    static const int np1 = getenv("PS_RS_NP") ? atoi(getenv("PS_RS_NP")) : 2;   // tuning knob (5184 only)
+    if (s->row_rs == 1 && np1 == 1) go(k_row_inv_rs<16, 18, 18, 1>, Rs<16, 18, 18>::NTHR, 1, RsInvLds<16, 18, 18>::bytes(1));
+    else if (s->row_rs == 1) go(k_row_inv_rs<16, 18, 18, 2>, Rs<16, 18, 18>::NTHR, 2, RsInvLds<16, 18, 18>::bytes(2));
+    else if (s->row_rs == 2) go(k_row_inv_rs<16, 18, 9, 2>, Rs<16, 18, 9>::NTHR, 2, RsInvLds<16, 18, 9>::bytes(2));
+    else go(k_row_inv_rs<16, 9, 9, 4>, Rs<16, 9, 9>::NTHR, 4, RsInvLds<16, 9, 9>::bytes(4));
   } else if (s->row_plan.generic)
     hipLaunchKernelGGL((k_row_inv<true, false>), grid, dim3(thr), lds, s->stream, a);
   else if (s->row_big)
@@ -455,7 +458,11 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     return fail(ps_fail(PS_ERR_UNSUPPORTED, "pad size %d exceeds the LDS-resident row limit", s->Pf));
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
-  if (s->Pf == Rs<16, 18, 18>::L && getenv("PS_NO_RS") == nullptr) s->row_rs = 1;
+  if (getenv("PS_NO_RS") == nullptr) {
+    if (s->Pf == Rs<16, 18, 18>::L) s->row_rs = 1;
+    else if (s->Pf == Rs<16, 18, 9>::L) s->row_rs = 2;
+    else if (s->Pf == Rs<16, 9, 9>::L) s->row_rs = 3;
+  }
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;

@@ -165,7 +165,8 @@ int main(int argc, char** argv) {
   double worst = 0;
   if (argc > 1 && !strcmp(argv[1], "rs")) {
     for (double e : {run_rs<16, 18, 18, PS_FWD>(), run_rs<16, 18, 18, PS_INV>(),
-                     run_rs<16, 9, 8, PS_FWD>(), run_rs<16, 16, 18, PS_INV>()}) {
+                     run_rs<16, 9, 8, PS_FWD>(), run_rs<16, 16, 18, PS_INV>(),
+                     run_rs<16, 18, 9, PS_INV>(), run_rs<16, 9, 9, PS_INV>()}) {
       if (e < 0) return 2;
       worst = e > worst ? e : worst;
     }
