@@ -168,3 +168,98 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   }
 }
 
+
+// ------------------------------------------------------------ forward rows
+// Two real rows (ra, rb) -> z = a + i b, loaded by the first stage straight from the source
+// (zero outside the row/column maps) -> three register stages -> Z in natural order, thread j
+// holding k = j + q T3.  A_k = (Z_k + conj Z_{L-k})/2 and B_k = (Z_k - conj Z_{L-k})/(2i) need
+// the mirrored element, which lives in another thread: one more exchange through LDS (real
+// parts, then imaginary parts), then coalesced 16-byte stores of the half spectra (k <= L/2).
+// Row pairs without a live source row are neither transformed nor written (the column pass
+// is told the same live-row window), exactly like k_row_fwd.
+template <int R1, int R2, int R3, int NP>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowFwdArgs a) {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  constexpr int L = S::L;
+  if (pred_skip(a.pred)) return;
+  const int half = threadIdx.x / S::NTHR;
+  const int pair = blockIdx.x * NP + half;
+  const int ra = 2 * pair, rb = ra + 1;
+  if (ra >= a.P) return;   // ended waves do not take part in the barriers below
+  double* ex = reinterpret_cast<double*>(ps_lds_raw) + half * (Y::XW + Y::RED);
+  const int j = threadIdx.x - half * S::NTHR;
+  const double* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
+  cplx* dst = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
+  const int rlo = a.rowrange ? a.rowrange[2 * blockIdx.y] : 0;
+  const int rhi = a.rowrange ? a.rowrange[2 * blockIdx.y + 1] : 0x7fffffff;
+  auto srow = [&](int r) {
+    const int sr = r < a.P ? src_map(a.rmap, r) : -1;
+    return (sr < rlo || sr > rhi) ? -1 : sr;
+  };
+  const int sa = srow(ra), sb = srow(rb);
+  cplx* da = dst + (int64_t)ra * a.ld;
+  cplx* db = dst + (int64_t)rb * a.ld;
+  const bool hasb = rb < a.P;
+  if (sa < 0 && sb < 0) {   // uniform per row pair
+    if (a.skip_zero) return;
+    const cplx z = make_double2(0.0, 0.0);
+    for (int k = j; k < a.H; k += S::NTHR) {
+      da[k] = z;
+      if (hasb) db[k] = z;
+    }
+    return;
+  }
+  const FftProg& P = a.prog;
+  const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
+  const cplx w3 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
+  cplx x[S::RMAX];
+  if (j < S::T1) {
+    const double* pa = src + (int64_t)(sa >= 0 ? sa : 0) * a.src_ld;
+    const double* pb = src + (int64_t)(sb >= 0 ? sb : 0) * a.src_ld;
+#pragma unroll
+    for (int q = 0; q < R1; ++q) {
+      const int sc = src_map(a.cmap, j + q * S::T1);
+      const bool ok = sc >= 0;
+      const int c = ok ? sc : 0;
+      const double va = pa[c], vb = pb[c];          // always in bounds; masked below
+      x[q] = make_double2((ok && sa >= 0) ? va : 0.0, (ok && sb >= 0) ? vb : 0.0);
+    }
+    bfly<R1, PS_FWD>(x);
+  }
+  rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);
+  // mirrored elements through LDS: Z_k of thread j sits at word k = j + q T3
+  cplx zm[R3 / 2 + 1];
+  constexpr int NQ = R3 / 2 + 1;   // slots q with j + q T3 <= L/2 for some j
+  __syncthreads();
+  if (j < S::T3) {
+#pragma unroll
+    for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].x;
+  }
+  __syncthreads();
+  if (j < S::T3) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int k = j + q * S::T3;
+      zm[q].x = ex[k ? L - k : 0];
+    }
+  }
+  __syncthreads();
+  if (j < S::T3) {
+#pragma unroll
+    for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].y;
+  }
+  __syncthreads();
+  if (j < S::T3) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int k = j + q * S::T3;
+      zm[q].y = ex[k ? L - k : 0];
+      if (k <= L / 2) {
+        const cplx zk = x[q];
+        da[k] = make_double2(0.5 * (zk.x + zm[q].x), 0.5 * (zk.y - zm[q].y));
+        if (hasb) db[k] = make_double2(0.5 * (zk.y + zm[q].y), -0.5 * (zk.x - zm[q].x));
+      }
+    }
+  }
+}

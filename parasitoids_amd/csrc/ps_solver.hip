@@ -173,7 +173,7 @@ static int set_lds_attr() {
                       (const void*)k_col<PS_FWD, false>, (const void*)k_col<PS_FWD, true>,
                       (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>,
                       (const void*)k_col_fused<false>, (const void*)k_col_fused<true>,
-                      (const void*)k_row_inv_rs<16, 18, 18, 2>};
+                      (const void*)k_row_inv_rs<16, 18, 18, 2>, (const void*)k_row_fwd_rs<16, 18, 18, 2>};
   for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   done = true;
   return PS_OK;
@@ -199,7 +199,14 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, pred ? PS_PROF_REFFT : PS_PROF_ROW_FWD);
-  if (s->row_plan.generic)
+  if (s->row_rs != 0 && getenv("PS_NO_RS_FWD") == nullptr) {
+    auto go = [&](auto kern, int nthr, int np, size_t lds_bytes) {
+      hipLaunchKernelGGL(kern, dim3((npairs + np - 1) / np, batch), dim3(nthr * np), lds_bytes, s->stream, a);
+    };
+    if (s->row_rs == 1) go(k_row_fwd_rs<16, 18, 18, 2>, Rs<16, 18, 18>::NTHR, 2, RsInvLds<16, 18, 18>::bytes(2));
+    else if (s->row_rs == 2) go(k_row_fwd_rs<16, 18, 9, 2>, Rs<16, 18, 9>::NTHR, 2, RsInvLds<16, 18, 9>::bytes(2));
+    else go(k_row_fwd_rs<16, 9, 9, 4>, Rs<16, 9, 9>::NTHR, 4, RsInvLds<16, 9, 9>::bytes(4));
+  } else if (s->row_plan.generic)
     hipLaunchKernelGGL((k_row_fwd<true, false>), grid, dim3(thr), lds, s->stream, a);
   else if (s->row_big)
     hipLaunchKernelGGL((k_row_fwd<false, true>), grid, dim3(thr), lds, s->stream, a);

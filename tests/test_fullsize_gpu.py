@@ -152,3 +152,32 @@ def test_chain_with_flags_at_awkward_sizes(hip_lib, R, K, mode):
             assert bool(st[d].flag) == bool(trace['flags'][d])
             assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
     s.close()
+
+
+@pytest.mark.parametrize('R,K,nd', [(512, 513, 6), (1024, 1025, 4), (2048, 2049, 3)])
+def test_register_resident_row_kernels_match_lds_kernels(hip_lib, monkeypatch, R, K, nd):
+    '''fft_rs.h kernels (sizes 1296, 2592, 5184: forward and inverse rows, incl. the re-FFT of
+    flagged days) against the LDS-resident program on the same fast size: same flags, fields
+    equal to round-off.'''
+    from parasitoids_amd import synthetic
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=R, sigma=(5.0, 15.0), shift=K // 4)
+    # two blobs, one near the edge so that days flag and the re-FFT path runs
+    state = sparse.coo_matrix(([0.7, 0.3], ([R, N - 20], [R, 30])), shape=(N, N))
+    out = []
+    for rs in (False, True):
+        if rs:
+            monkeypatch.delenv('PS_NO_RS', raising=False)
+        else:
+            monkeypatch.setenv('PS_NO_RS', '1')
+        s = hip_lib.HipSolve(state, [K, K], mode='fast')
+        assert s.fft_len in (1296, 2592, 5184)
+        s.set_kernels(kernels)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        out.append(([s.dense(0, d) for d in range(nd)], [bool(x.flag) for x in st], [x.nnz for x in st]))
+        s.close()
+    assert out[0][1] == out[1][1] and any(out[0][1])
+    for a, b in zip(out[0][0], out[1][0]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
+    assert out[0][2] == out[1][2]
