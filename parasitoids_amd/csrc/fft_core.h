@@ -289,6 +289,43 @@ PS_HD void bfly18(cplx* x) {
   }
 }
 
+// Prime-factor (Good-Thomas) butterfly for R = A * B with gcd(A, B) = 1: no internal
+// twiddles, only the index maps  n = (B n1 + A n2) mod R  (input)  and  k = k1 (mod A),
+// k = k2 (mod B)  (output, CRT) -- all compile-time constants after unrolling.
+constexpr int ps_modinv(int a, int m) {
+  for (int v = 1; v < m; ++v)
+    if ((a * v) % m == 1) return v;
+  return 1;
+}
+template <int R, int DIR>
+PS_HD void bfly(cplx* x);
+
+template <int A, int B, int DIR>
+PS_HD void bfly_pfa(cplx* x) {
+  constexpr int N = A * B;
+  constexpr int ca = B * ps_modinv(B % A, A);   // == 1 mod A, == 0 mod B
+  constexpr int cb = A * ps_modinv(A % B, B);   // == 0 mod A, == 1 mod B
+  cplx y[A][B];
+#pragma unroll
+  for (int n1 = 0; n1 < A; ++n1) {
+    cplx t[B];
+#pragma unroll
+    for (int n2 = 0; n2 < B; ++n2) t[n2] = x[(B * n1 + A * n2) % N];
+    bfly<B, DIR>(t);
+#pragma unroll
+    for (int k2 = 0; k2 < B; ++k2) y[n1][k2] = t[k2];
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < B; ++k2) {
+    cplx t[A];
+#pragma unroll
+    for (int n1 = 0; n1 < A; ++n1) t[n1] = y[n1][k2];
+    bfly<A, DIR>(t);
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) x[(k1 * ca + k2 * cb) % N] = t[k1];
+  }
+}
+
 template <int R, int DIR>
 PS_HD void bfly(cplx* x) {
   if (R == 2) bfly2<DIR>(x);
@@ -298,8 +335,13 @@ PS_HD void bfly(cplx* x) {
   else if (R == 7) bfly_odd<7, DIR>(x);
   else if (R == 8) bfly8<DIR>(x);
   else if (R == 9) bfly9<DIR>(x);
+  else if (R == 10) bfly_pfa<2, 5, DIR>(x);
+  else if (R == 12) bfly_pfa<3, 4, DIR>(x);
+  else if (R == 14) bfly_pfa<2, 7, DIR>(x);
+  else if (R == 15) bfly_pfa<3, 5, DIR>(x);
   else if (R == 16) bfly16<DIR>(x);
   else if (R == 18) bfly18<DIR>(x);
+  else if (R == 20) bfly_pfa<4, 5, DIR>(x);
 }
 
 // ------------------------------------------------------------------ twiddles

@@ -154,7 +154,11 @@ def test_chain_with_flags_at_awkward_sizes(hip_lib, R, K, mode):
     s.close()
 
 
-@pytest.mark.parametrize('R,K,nd', [(512, 513, 6), (1024, 1025, 4), (2048, 2049, 3)])
+@pytest.mark.parametrize('R,K,nd', [(512, 513, 6), (1024, 1025, 4), (2048, 2049, 3),
+                                    (800, 601, 4),      # 1920 = 16*12*10 (prime-factor radices)
+                                    (1400, 1101, 3),    # 3360 = 16*15*14
+                                    (2048, 3201, 2),    # 5760 = 16*20*18
+                                    (2600, 2299, 2)])   # 6400 = 16*20*20
 def test_register_resident_row_kernels_match_lds_kernels(hip_lib, monkeypatch, R, K, nd):
     '''fft_rs.h kernels (sizes 1296, 2592, 5184: forward and inverse rows, incl. the re-FFT of
     flagged days) against the LDS-resident program on the same fast size: same flags, fields
@@ -171,12 +175,15 @@ def test_register_resident_row_kernels_match_lds_kernels(hip_lib, monkeypatch, R
         else:
             monkeypatch.setenv('PS_NO_RS', '1')
         s = hip_lib.HipSolve(state, [K, K], mode='fast')
-        assert s.fft_len in (1296, 2592, 5184)
+        assert s.fft_len in (1296, 2592, 5184, 1920, 3360, 5760, 6400)
+        out.append(s.fft_len)
         s.set_kernels(kernels)
         s.run_chain(renorm=True)
         st = s.chain_stats(0, nd)
         out.append(([s.dense(0, d) for d in range(nd)], [bool(x.flag) for x in st], [x.nnz for x in st]))
         s.close()
+    assert out[0] == out[2]          # same FFT size with and without the rs kernels
+    out = [out[1], out[3]]
     assert out[0][1] == out[1][1] and any(out[0][1])
     for a, b in zip(out[0][0], out[1][0]):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
