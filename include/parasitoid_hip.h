@@ -62,6 +62,9 @@ int ps_device_info(int device, char* name, int n, int* cus, int64_t* hbm_bytes);
 
 /* CudaSolve.__init__ shape logic (cuda_lib.py:26-28): pad = dom_len + max_shape//2. */
 int ps_solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode);
+/* FFT size a PS_MODE_FAST solver would use for this domain and kernel shape (no device needed):
+ * lets a caller size max_shape so that one solver serves a range of kernel shapes. */
+int ps_fast_size(int dom_len, int max_shape);
 int ps_solver_destroy(ps_solver* s);
 /* P = reference torus, Pfft = transform size in use, H = Pfft/2+1 */
 int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H);

@@ -466,6 +466,23 @@ static int refft_if_flag(ps_solver* s, const double* rec, cplx* hat, int slot) {
                s->padmax.p + slot);
 }
 
+// fast-mode FFT size for a reference pad P: the smallest even 7-smooth size, or a size served
+// by the register-resident row kernels (row passes 35-50 % faster) when that costs at most
+// 8 % more work
+static int fast_size(int Pref) {
+  int Pf = ps_next_fast_len(Pref);
+  if (getenv("PS_NO_RS") == nullptr) {
+    const int L = rs_next_size(Pref);
+    if (L > 0 && (double)L * L <= 1.08 * (double)Pf * Pf) Pf = L;
+  }
+  return Pf;
+}
+
+extern "C" int ps_fast_size(int dom_len, int max_shape) {
+  if (dom_len < 1 || max_shape < 1) return 0;
+  return fast_size(dom_len + max_shape / 2);
+}
+
 // ------------------------------------------------------------------- create
 extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode) {
   if (!out) return ps_fail(PS_ERR_BAD_ARG, "null output handle");
@@ -480,13 +497,7 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   s->M = max_shape / 2;
   s->Pref = dom_len + s->M;  // CalcSol.py:20-21, cuda_lib.py:26-28
   s->mode = mode;
-  s->Pf = mode == PS_MODE_FAST ? ps_next_fast_len(s->Pref) : s->Pref;
-  if (mode == PS_MODE_FAST && getenv("PS_NO_RS") == nullptr) {
-    // prefer a size served by the register-resident row kernels (row passes 35-50 % faster)
-    // when it costs at most 8 % more work than the smallest 7-smooth size
-    const int L = rs_next_size(s->Pref);
-    if (L > 0 && (double)L * L <= 1.08 * (double)s->Pf * s->Pf) s->Pf = L;
-  }
+  s->Pf = mode == PS_MODE_FAST ? fast_size(s->Pref) : s->Pref;
   s->H = s->Pf / 2 + 1;
   s->ld = (s->H + 7) & ~7;
   auto fail = [&](int rc) {

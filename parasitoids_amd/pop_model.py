@@ -43,7 +43,22 @@ class PopModel():
         self.model.close()
 
     def _solver_for(self, max_shape):
+        """A solver whose torus holds kernels up to `max_shape`.  In exact mode the torus is the
+        reference's N + max_shape//2, so solvers are keyed by max_shape.  In fast mode any
+        torus >= that works: the solver is created for the largest max_shape that still maps
+        to the same FFT size, so one solver (plans + ~GBs of buffers) serves every evaluation
+        whose kernels fit -- the kernel extent moves with the sampled diffusion parameters."""
         key = int(max_shape)
+        N = 2 * self.rad_res + 1
+        if self.mode == 'fast':
+            lib = L.load()
+            pf = int(lib.ps_fast_size(N, key))
+            key = 2 * (pf - N) + 1
+            if lib.ps_fast_size(N, key) != pf:      # never leave the size class
+                key = int(max_shape)
+            fits = [k for k in self._solvers if k >= int(max_shape) and k <= key]
+            if fits:
+                key = min(fits)
         s = self._solvers.pop(key, None)
         if s is None:
             if len(self._solvers) >= self._max_solvers:
