@@ -101,8 +101,10 @@ static __global__ void k_row_stats(const double* __restrict__ rec, int N, double
   if (threadIdx.x == 0) { rowsum[r] = ssum[0]; rowcnt[r] = scnt[0]; }
 }
 
-// exclusive scan of per-row counts (single block, N <= ~16k rows)
-static __global__ void k_scan_rows(const long long* rowcnt, int N, long long* rowoff) {
+// exclusive scan of per-row counts (one block per record: blockIdx.x-th array of N counts)
+static __global__ void k_scan_rows(const long long* rowcnt_, int N, long long* rowoff_) {
+  const long long* rowcnt = rowcnt_ + (int64_t)blockIdx.x * N;
+  long long* rowoff = rowoff_ + (int64_t)blockIdx.x * N;
   __shared__ long long part[1024];
   const int T = blockDim.x;
   const int per = (N + T - 1) / T;

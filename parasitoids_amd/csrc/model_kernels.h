@@ -644,6 +644,40 @@ __global__ void k_pmf_compact(const double* __restrict__ pmf, int N, double negv
   }
 }
 
+// all days of a batch in one launch (blockIdx.y = day): threshold, renormalisation shift and
+// shrink offset come from the day's DayInfo, the output position from `off`
+__global__ void k_pmf_compact_batch(const double* __restrict__ pmf_, int N, double negval, int rad_res,
+                                    const DayInfo* __restrict__ dinfo, const long long* __restrict__ off,
+                                    const long long* __restrict__ rowoff_, int* orow, int* ocol, double* oval) {
+  const int d = blockIdx.y;
+  const DayInfo& di = dinfo[d];
+  if (di.status != 0 || di.nnz == 0) return;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= N) return;
+  const double* pmf = pmf_ + (int64_t)d * N * N;
+  const double delta = di.delta;
+  const int idx_off = -rad_res + di.rad;
+  long long base = off[d] + rowoff_[(int64_t)d * N + wave];
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int c = c0 + lane;
+    double t = 0.0;
+    bool keep = false;
+    if (c < N) {
+      t = pmf[(int64_t)wave * N + c];
+      keep = (t != 0.0) && !(t < negval);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+      const int o = __popcll(m & ((1ull << lane) - 1ull));
+      orow[base + o] = wave + idx_off;
+      ocol[base + o] = c + idx_off;
+      oval[base + o] = t + delta;
+    }
+    base += __popcll(m);
+  }
+}
+
 // get_mvn_cdf_values (ParasitoidModel.py:311-380) for one (cell, mu, S)
 __global__ void k_mvn_cdf_values(BvuRule rule, double sdx, double sdy, double mux, double muy,
                                  double cell, int hmax, int* Hout, double* out, long long cap) {

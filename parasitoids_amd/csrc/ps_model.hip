@@ -21,7 +21,7 @@ struct ps_model {
   int nd = 0, N = 0, R = 0;
   DevBuf<int> day_idx;
   DevBuf<double> start_time, hprob, scratch, pmf, psum, pmin, rowsum;
-  DevBuf<long long> rowcnt, rowoff;
+  DevBuf<long long> rowcnt, rowoff, doff;
   DevBuf<int> rowrad;
   DevBuf<PeriodInfo> pinfo;
   DevBuf<DayInfo> dinfo;
@@ -107,7 +107,7 @@ extern "C" int ps_model_destroy(ps_model* m) {
   }
   m->wind.release(); m->day_keys.release(); m->day_idx.release(); m->start_time.release();
   m->hprob.release(); m->scratch.release(); m->pmf.release(); m->psum.release(); m->pmin.release();
-  m->rowsum.release(); m->rowcnt.release(); m->rowoff.release(); m->rowrad.release();
+  m->rowsum.release(); m->rowcnt.release(); m->rowoff.release(); m->doff.release(); m->rowrad.release();
   m->pinfo.release(); m->dinfo.release(); m->orow.release(); m->ocol.release(); m->oval.release();
   m->stamp.release(); m->stampH.release();
   delete m;
@@ -225,14 +225,18 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
   PS_TRY(m->orow.ensure(std::max<int64_t>(tot, 1)));
   PS_TRY(m->ocol.ensure(std::max<int64_t>(tot, 1)));
   PS_TRY(m->oval.ensure(std::max<int64_t>(tot, 1)));
-  for (int d = 0; d < nd; ++d) {
-    const DayInfo& di = m->hinfo[d];
-    if (di.status != 0 || di.nnz == 0) continue;
-    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, m->rowcnt.p + (int64_t)d * N, N, m->rowoff.p);
+  if (tot > 0) {   // one scan and one compaction launch for the whole batch of days
+    PS_TRY(m->rowoff.ensure((size_t)nd * N));
+    PS_TRY(m->doff.ensure((size_t)nd + 1));
+    {
+      std::vector<long long> o64(m->off.begin(), m->off.end());
+      PS_HIP(hipMemcpyAsync(m->doff.p, o64.data(), o64.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+      PS_HIP(hipStreamSynchronize(st));   // o64 is a temporary
+    }
+    hipLaunchKernelGGL(k_scan_rows, dim3(nd), dim3(1024), 0, st, m->rowcnt.p, N, m->rowoff.p);
     PS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_pmf_compact, dim3((N * 64 + 255) / 256), dim3(256), 0, st, m->pmf.p + (int64_t)d * n2, N,
-                       1e-8, di.delta, -rad_res + di.rad, m->rowoff.p, m->orow.p + m->off[d],
-                       m->ocol.p + m->off[d], m->oval.p + m->off[d]);
+    hipLaunchKernelGGL(k_pmf_compact_batch, dim3((N * 64 + 255) / 256, nd), dim3(256), 0, st, m->pmf.p, N, 1e-8,
+                       rad_res, m->dinfo.p, m->doff.p, m->rowoff.p, m->orow.p, m->ocol.p, m->oval.p);
     PS_HIP(hipGetLastError());
   }
   PS_HIP(hipStreamSynchronize(st));
