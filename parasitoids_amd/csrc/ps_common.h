@@ -39,6 +39,15 @@ inline int ps_fail(int code, const char* fmt, ...) {
     if (rc_ != PS_OK) return rc_; \
   } while (0)
 
+// Device memory goes through a small caching allocator (ps_solver.hip): an MCMC run creates
+// and destroys a solver whenever the kernel extent changes, and hipMalloc/hipFree of its
+// ~40 buffers cost more than the evaluation itself.  Freed blocks are kept per device (up to
+// PS_POOL_GB, default 16) and handed out again for requests of about the same size.
+// ps_dev_free assumes the block is idle: callers synchronise first (ps_dev_quiesce).
+hipError_t ps_dev_malloc(void** p, size_t bytes);
+void ps_dev_free(void* p);
+void ps_dev_quiesce();   // hipDeviceSynchronize: nothing in flight may still use a block about to be freed
+
 // growable device buffer
 template <typename T>
 struct DevBuf {
@@ -46,18 +55,21 @@ struct DevBuf {
   size_t cap = 0;
   int ensure(size_t n) {
     if (n <= cap) return PS_OK;
-    if (p) (void)hipFree(p);
+    if (p) {
+      ps_dev_quiesce();   // queued work may still read the old block
+      ps_dev_free(p);
+    }
     p = nullptr;
     cap = 0;
-    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    hipError_t e = ps_dev_malloc((void**)&p, n * sizeof(T));
     if (e != hipSuccess)
       return ps_fail(e == hipErrorOutOfMemory ? PS_ERR_OOM : PS_ERR_HIP,
-                     "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+                     "device allocation of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
     cap = n;
     return PS_OK;
   }
-  void release() {
-    if (p) (void)hipFree(p);
+  void release() {   // callers quiesce first (destroy paths)
+    if (p) ps_dev_free(p);
     p = nullptr;
     cap = 0;
   }

@@ -105,6 +105,7 @@ extern "C" int ps_model_destroy(ps_model* m) {
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamDestroy(m->stream);
   }
+  ps_dev_quiesce();
   m->wind.release(); m->day_keys.release(); m->day_idx.release(); m->start_time.release();
   m->hprob.release(); m->scratch.release(); m->pmf.release(); m->psum.release(); m->pmin.release();
   m->rowsum.release(); m->rowcnt.release(); m->rowoff.release(); m->doff.release(); m->rowrad.release();

@@ -41,6 +41,84 @@ int ps_use_device(int device) {
 }
 
 static const int kMaxLds = 160 * 1024;
+
+// ---------------------------------------------------------------- caching device allocator
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::map<int, std::multimap<size_t, void*>> free_;   // device -> size -> block
+  std::unordered_map<void*, std::pair<int, size_t>> live;   // block -> (device, size)
+  size_t cached = 0;
+  size_t limit() {
+    static const size_t gb = getenv("PS_POOL_GB") ? (size_t)atoi(getenv("PS_POOL_GB")) : 16;
+    return gb << 30;
+  }
+  void flush_locked() {
+    for (auto& dv : free_)
+      for (auto& kv : dv.second) (void)hipFree(kv.second);
+    free_.clear();
+    cached = 0;
+  }
+};
+DevPool& pool() {
+  static DevPool* p = new DevPool();   // never destroyed: blocks may outlive static teardown order
+  return *p;
+}
+size_t round_size(size_t b) {
+  const size_t g = b >= (1u << 20) ? (size_t)1 << 20 : 256;
+  return (b + g - 1) / g * g;
+}
+}  // namespace
+
+hipError_t ps_dev_malloc(void** out, size_t bytes) {
+  DevPool& P = pool();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t want = round_size(bytes ? bytes : 1);
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto& fr = P.free_[dev];
+  auto it = fr.lower_bound(want);
+  if (it != fr.end() && it->first <= want + want / 4 + (1u << 20)) {
+    *out = it->second;
+    P.live[*out] = {dev, it->first};
+    P.cached -= it->first;
+    fr.erase(it);
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(out, want);
+  if (e != hipSuccess) {   // give the cached blocks back and try once more
+    (void)hipGetLastError();
+    P.flush_locked();
+    e = hipMalloc(out, want);
+  }
+  if (e == hipSuccess) P.live[*out] = {dev, want};
+  return e;
+}
+
+void ps_dev_free(void* p) {
+  if (!p) return;
+  DevPool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.live.find(p);
+  if (it == P.live.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  const int dev = it->second.first;
+  const size_t sz = it->second.second;
+  P.live.erase(it);
+  if (P.cached + sz > P.limit()) {
+    (void)hipFree(p);
+    return;
+  }
+  P.free_[dev].emplace(sz, p);
+  P.cached += sz;
+}
+
+void ps_dev_quiesce() { (void)hipDeviceSynchronize(); }
 static const int kPredGrid = 512;  // grid of the flag-conditional (usually empty) launches
 #define PS_PROF_NCLS 8
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
@@ -432,7 +510,7 @@ static int ensure_record(ps_solver* s, int kind, int idx) {
   auto& v = s->recs[kind];
   if ((int)v.size() <= idx) v.resize(idx + 1, nullptr);
   if (!v[idx]) {
-    hipError_t e = hipMalloc((void**)&v[idx], (size_t)s->N * s->N * sizeof(double));
+    hipError_t e = ps_dev_malloc((void**)&v[idx], (size_t)s->N * s->N * sizeof(double));
     if (e != hipSuccess) return ps_fail(PS_ERR_OOM, "record allocation failed: %s", hipGetErrorString(e));
   }
   return PS_OK;
@@ -579,13 +657,14 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
     (void)hipStreamSynchronize(s->stream);
     (void)hipStreamDestroy(s->stream);
   }
+  ps_dev_quiesce();
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
   s->tp_lo.release(); s->tp_hi.release();
   s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release();
   s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release(); s->krange.release();
   for (auto& v : s->recs)
     for (double* p : v)
-      if (p) (void)hipFree(p);
+      if (p) ps_dev_free(p);
   s->rowsum.release(); s->rowcnt.release(); s->rowoff.release(); s->padmax.release();
   s->dstats.release();
   s->orow.release(); s->ocol.release(); s->oval.release(); s->wptr.release(); s->wval.release();
