@@ -14,6 +14,15 @@ static __global__ void k_scatter_coo(const int* __restrict__ row, const int* __r
     atomicAdd(&dst[(int64_t)(row[i] + roff) * ld + col[i] + coff], val[i]);
 }
 
+// zero rows [r0, r1] of each of gridDim.y consecutive K x K blocks (the band of staging rows
+// some kernel of the chunk writes: the row pass reads nothing else)
+static __global__ void k_zero_band(double* dst, int K, int r0, int r1) {
+  double* base = dst + (int64_t)blockIdx.y * K * K + (int64_t)r0 * K;
+  const int64_t n = (int64_t)(r1 - r0 + 1) * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    base[i] = 0.0;
+}
+
 // batched form: day d = blockIdx.y scatters its triplets [koff[d], koff[d+1]) into the d-th
 // K x K staging block, centred (offset M - kshape[d]/2): one launch per chunk of kernels
 static __global__ void k_scatter_coo_batch(const int* __restrict__ row, const int* __restrict__ col,

@@ -760,7 +760,7 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   PS_TRY(s->Bhat.ensure(spec * count));
   PS_TRY(ensure_temps(s, count));
   // zero only the band of staging rows some kernel of the chunk writes (the row pass reads
-  // nothing else, see krange), in one strided memset; then one batched scatter launch
+  // nothing else, see krange) with one small kernel, then one batched scatter launch
   int blo = K, bhi = -1;
   int64_t maxn = 0;
   for (int d = first; d < first + count; ++d) {
@@ -773,8 +773,10 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   if (bhi >= blo) {
     blo = std::max(blo, 0);
     bhi = std::min(bhi, K - 1);
-    PS_HIP(hipMemset2DAsync(s->kdense.p + (size_t)blo * K, (size_t)K * K * sizeof(double), 0,
-                            (size_t)(bhi - blo + 1) * K * sizeof(double), (size_t)count, s->stream));
+    const int64_t n = (int64_t)(bhi - blo + 1) * K;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_zero_band, dim3(blocks, count), dim3(256), 0, s->stream, s->kdense.p, K, blo, bhi);
+    PS_HIP(hipGetLastError());
   }
   if (maxn > 0) {
     const int thr = 256;
