@@ -188,3 +188,63 @@ def test_register_resident_row_kernels_match_lds_kernels(hip_lib, monkeypatch, R
     for a, b in zip(out[0][0], out[1][0]):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
     assert out[0][2] == out[1][2]
+
+
+def _rs_sizes():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, 'parasitoids_amd', 'csrc', 'fft_rs_sizes.h')).read()
+    return sorted(16 * int(a) * int(b) for a, b in re.findall(r'X\((\d+), (\d+)\)', txt))
+
+
+def test_every_register_resident_size(hip_lib, monkeypatch):
+    '''One short flagged chain per size of fft_rs_sizes.h (all 43 forward + inverse kernel
+    instantiations) against the LDS-resident program on the same FFT size.'''
+    from parasitoids_amd import synthetic, _lib as L
+    lib = L.load()
+    sizes = _rs_sizes()
+    assert len(sizes) >= 40 and 5184 in sizes and 1296 in sizes
+    done = 0
+    for Lfft in sizes:
+        # a domain / kernel shape whose fast size is exactly Lfft with and without the rs kernels
+        cand = None
+        for K in (2 * (Lfft // 6) + 1, 2 * (Lfft // 8) + 1, 2 * (Lfft // 5) + 1):
+            N = Lfft - K // 2
+            N -= (N + 1) % 2                       # odd domain
+            for dn in (0, 2, 4, 6):
+                n = N - dn
+                monkeypatch.delenv('PS_NO_RS', raising=False)
+                a = lib.ps_fast_size(n, K)
+                monkeypatch.setenv('PS_NO_RS', '1')
+                b = lib.ps_fast_size(n, K)
+                if a == Lfft and b == Lfft:
+                    cand = (n, K)
+                    break
+            if cand:
+                break
+        if cand is None:
+            continue                               # the 7-smooth neighbour is smaller: rs size unused there
+        N, K = cand
+        R = N // 2
+        _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=2, seed=Lfft, sigma=(4.0, 9.0), shift=K // 5)
+        state = sparse.coo_matrix(([0.6, 0.4], ([R, N - 12], [R, 20])), shape=(N, N))
+        res = []
+        for rs in (False, True):
+            if rs:
+                monkeypatch.delenv('PS_NO_RS', raising=False)
+            else:
+                monkeypatch.setenv('PS_NO_RS', '1')
+            s = hip_lib.HipSolve(state, [K, K], mode='fast')
+            assert s.fft_len == Lfft
+            s.set_kernels(kernels)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, 2)
+            res.append(([s.dense(0, d) for d in range(2)], [bool(x.flag) for x in st]))
+            s.close()
+        assert res[0][1] == res[1][1], Lfft
+        for a, b in zip(res[0][0], res[1][0]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-14, err_msg=str(Lfft))
+        done += 1
+    monkeypatch.delenv('PS_NO_RS', raising=False)
+    assert done >= 35
