@@ -643,6 +643,7 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   const size_t spec = (size_t)s->Pf * s->ld;
   const size_t budget = (size_t)3 << 30;  // bytes of batched kernel spectra per chunk
   s->chunk_days = (int)std::max<size_t>(1, std::min<size_t>(64, budget / (spec * sizeof(cplx))));
+  if (const char* e = getenv("PS_CHUNK_DAYS")) s->chunk_days = std::max(1, atoi(e));   // tuning knob
   if ((rc = s->Ahat.ensure(spec))) return fail(rc);
   if ((rc = s->rowoff.ensure(s->N))) return fail(rc);
   if ((rc = ensure_stats(s, 4))) return fail(rc);
