@@ -41,3 +41,32 @@ def test_pop_model_kalbar_r400(golden, golden_dir):
     ref = pm.population(3)
     assert abs(v[0] - ref[400, 400]) < 1e-9 and abs(v[1] - ref[390, 410]) < 1e-9
     pm.close()
+
+
+def test_pop_model_fast_mode_reuses_solvers_and_matches_exact():
+    '''fast mode keeps one solver per FFT size class and reuses it when the kernel extent moves
+    with the diffusion parameters; the populations must agree with exact-mode evaluations of
+    the same parameters to the fast-mode tolerance (the tori differ only in sub-threshold dust).'''
+    import warnings
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.pop_model import PopModel
+    from helpers import HP, DLP, MU_R, NPER
+    warnings.simplefilter('ignore', RuntimeWarning)
+    root = os.path.dirname(os.path.abspath(__file__))
+    wd, days = PM.get_wind_data(os.path.join(root, 'golden', 'data', 'kalbar'), 30, '00:00')
+    fast = PopModel(wd, days, domain_info=(10000.0, 200), r_number=130000, mode='fast')
+    exact = PopModel(wd, days, domain_info=(10000.0, 200), r_number=130000, mode='exact')
+    sizes = set()
+    for sx, sy in ((171.82, 144.58), (150.0, 130.0), (185.0, 160.0), (171.82, 144.58)):
+        dp = (sx, sy, 0.253)
+        sf = fast.evaluate(HP, dp, DLP, MU_R, NPER, ndays=8)
+        se = exact.evaluate(HP, dp, DLP, MU_R, NPER, ndays=8)
+        sizes.add(fast.solver.fft_len)
+        for (nf, tf), (ne, te) in zip(sf, se):
+            assert abs(tf - te) <= 1e-6 * max(te, 1.0)
+            assert abs(nf - ne) <= 0.002 * ne + 50        # entries right at the 1e-8 cut may flip
+        a = fast.population(7).toarray()
+        b = exact.population(7).toarray()
+        assert np.abs(a - b).max() <= 5e-8 * 130000
+    assert len(fast._solvers) <= 2 and len(sizes) <= 2     # kernel shapes moved, solvers did not
+    fast.close(); exact.close()
