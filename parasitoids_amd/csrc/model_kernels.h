@@ -363,102 +363,134 @@ __global__ void k_day_prep(ModelParams mp, const double* start_time, const Perio
 }
 
 // ---------------------------------------------------------------- accumulate
-// One workgroup per 16 x 16 pmf tile and day: PM_GROUPS groups of 320 threads.
-// Phase 0: all threads scan the day's windows and build the ordered list of periods that
-// touch the tile.  Phase 1: each group takes one listed period at a time and builds its
-// 17 x 17 corner grid in one round (289 <= 320 threads; the Phi factors of the 17 column /
-// 17 row edges are computed once) and the 256 cell masses; then the 256 cell owners add
-// hprob[t] * mass for the PM_GROUPS periods IN ASCENDING PERIOD ORDER -- the reference's
-// accumulation order (ParasitoidModel.py:539) is kept while PM_GROUPS periods are in
-// flight, which is what bounds the busiest (central) tiles.
-#define PM_GROUP_THREADS 320
-#define PM_GROUPS 3
-#define PM_TILE_THREADS (PM_GROUP_THREADS * PM_GROUPS)
+// pmf[window] += hprob[t] * stamp_t for every period t (ParasitoidModel.py:539-540), with the
+// reference's accumulation order per cell (ascending t) but the expensive part -- the corner
+// values of the bivariate normal -- fully parallel:
+//   k_tile_count / k_tile_fill   per 16 x 16 pmf tile: the ORDERED list of periods whose stamp
+//                                window touches the tile ("pairs"); two passes around a scan,
+//                                so that only real pairs are stored
+//   k_pair_masses                one wave per (tile, period) pair: the Phi factors of the needed
+//                                column/row edges, the BVU corner values of the part of the tile
+//                                under the window, the 256 cell masses times hprob[t] -> a 2 KB
+//                                record per pair.  Independent waves: no chain through a tile
+//   k_tile_accumulate            per tile: the records of its pairs added in list order with
+//                                explicit __dadd_rn (bit-identical to a sequential loop over t)
 #define PM_NC ((PM_TS + 1) * (PM_TS + 1))
-__global__ void __launch_bounds__(PM_TILE_THREADS)
-k_stamp_tiles(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo* __restrict__ dinfo,
-              double* pmf /*[nd][N][N]*/) {
-  const int d = blockIdx.z;
-  const DayInfo& di = dinfo[d];
-  const int N = mp.N, T = mp.T;
+#define PM_CELLS (PM_TS * PM_TS)
+
+__device__ __forceinline__ bool pm_tile_in_box(const DayInfo& di, int i0, int j0) {
+  return !(i0 > di.r1 || i0 + PM_TS - 1 < di.r0 || j0 > di.c1 || j0 + PM_TS - 1 < di.c0);
+}
+__device__ __forceinline__ bool pm_hits(const PeriodInfo& p, int i0, int j0) {
+  return !p.skip && !(p.rc + p.H < i0 || p.rc - p.H > i0 + PM_TS - 1 || p.cc + p.H < j0 ||
+                      p.cc - p.H > j0 + PM_TS - 1);
+}
+
+// tcnt[(d * nt + ty) * nt + tx] = number of periods touching the tile (256 threads)
+__global__ void __launch_bounds__(256)
+k_tile_count(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo* __restrict__ dinfo,
+             long long* __restrict__ tcnt) {
+  const int d = blockIdx.z, T = mp.T;
   const int i0 = blockIdx.y * PM_TS, j0 = blockIdx.x * PM_TS;
-  if (i0 > di.r1 || i0 + PM_TS - 1 < di.r0 || j0 > di.c1 || j0 + PM_TS - 1 < di.c0) return;
-  extern __shared__ int st_list[];  // [T] ordered period indices touching this tile
-  __shared__ double s_b[PM_GROUPS][PM_NC];
-  __shared__ double s_px[PM_GROUPS][PM_TS + 1], s_py[PM_GROUPS][PM_TS + 1];   // Phi(-h_a), Phi(-k_b)
-  __shared__ double s_hx[PM_GROUPS][PM_TS + 1], s_ky[PM_GROUPS][PM_TS + 1];   // h_a, k_b
-  __shared__ double s_mass[PM_GROUPS][PM_TS * PM_TS];
-  __shared__ int s_wcnt[PM_TILE_THREADS / 64], s_total;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile = ((int64_t)d * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  __shared__ int s_cnt[4];
+  int n = 0;
+  if (pm_tile_in_box(dinfo[d], i0, j0)) {
+    const PeriodInfo* pi = pinfo + (int64_t)d * T;
+    for (int t = threadIdx.x; t < T; t += 256) n += pm_hits(pi[t], i0, j0) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) tcnt[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// ordered list of the tile's periods at toff[tile] - base: period index and tile id per pair
+__global__ void __launch_bounds__(256)
+k_tile_fill(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo* __restrict__ dinfo,
+            const long long* __restrict__ tcnt, const long long* __restrict__ toff, int d0, long long base,
+            int* __restrict__ pair_t, int* __restrict__ pair_tile) {
+  const int d = d0 + blockIdx.z, T = mp.T;
+  const int i0 = blockIdx.y * PM_TS, j0 = blockIdx.x * PM_TS;
+  const int64_t tile = ((int64_t)d * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (tcnt[tile] == 0) return;
+  const long long out0 = toff[tile] - base;
   const PeriodInfo* pi = pinfo + (int64_t)d * T;
-  // ---- phase 0: ordered compaction of the overlapping periods
+  __shared__ int s_wcnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nlist = 0;
-  for (int t0 = 0; t0 < T; t0 += PM_TILE_THREADS) {
-    const int t = t0 + tid;
-    bool hit = false;
-    if (t < T) {
-      const PeriodInfo p = pi[t];
-      hit = !p.skip && !(p.rc + p.H < i0 || p.rc - p.H > i0 + PM_TS - 1 || p.cc + p.H < j0 ||
-                         p.cc - p.H > j0 + PM_TS - 1);
-    }
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const bool hit = t < T && pm_hits(pi[t], i0, j0);
     const unsigned long long m = __ballot(hit);
     if (lane == 0) s_wcnt[wave] = __popcll(m);
     __syncthreads();
-    int base = nlist;
-    for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-    if (hit) st_list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
-    if (tid == 0) {
-      int tot = 0;
-      for (int w = 0; w < PM_TILE_THREADS / 64; ++w) tot += s_wcnt[w];
-      s_total = tot;
+    int pos = nlist;
+    for (int w = 0; w < wave; ++w) pos += s_wcnt[w];
+    if (hit) {
+      const long long o = out0 + pos + __popcll(m & ((1ull << lane) - 1ull));
+      pair_t[o] = t;
+      pair_tile[o] = (int)(tile - (int64_t)d0 * gridDim.y * gridDim.x);
     }
+    nlist += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
     __syncthreads();
-    nlist += s_total;
   }
-  // ---- phase 1
-  const int g = tid / PM_GROUP_THREADS, gt = tid - g * PM_GROUP_THREADS;
-  const int li = gt / PM_TS, lj = gt % PM_TS;   // cell of this thread inside its group (gt < 256)
+}
+
+// one wave per pair (4 pairs per 256-thread workgroup, same phase structure -> plain barriers)
+__global__ void __launch_bounds__(256)
+k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int nt, long long npairs,
+              const int* __restrict__ pair_t, const int* __restrict__ pair_tile, double* __restrict__ hm) {
+  __shared__ double s_b[4][PM_NC];
+  __shared__ double s_px[4][PM_TS + 1], s_py[4][PM_TS + 1];   // Phi(-h_a), Phi(-k_b)
+  __shared__ double s_hx[4][PM_TS + 1], s_ky[4][PM_TS + 1];   // h_a, k_b
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long pr = (long long)blockIdx.x * 4 + g;
+  const bool have = pr < npairs;
   const double c = mp.cell;
-  double acc = 0.0;                              // owned by threads tid < 256 (group 0)
-  for (int q0 = 0; q0 < nlist; q0 += PM_GROUPS) {
-    const int q = q0 + g;
-    const bool have = q < nlist;
-    PeriodInfo p;
-    if (have) p = pi[st_list[q]];
-    // Only the part of the tile under the period's stamp window needs corner values: on
-    // average 60 % of the 17 x 17 grid (border tiles are half covered).  The needed
-    // sub-rectangle [a0, a0+na) x [b0, b0+nb) is enumerated contiguously, so whole waves
-    // drop out instead of lanes; the arithmetic of every value that is used is unchanged.
-    int a0 = 0, na = 0, b0 = 0, nb = 0;
-    if (have) {
-      const int ja0 = max(j0, p.cc - p.H), ja1 = min(j0 + PM_TS - 1, p.cc + p.H);
-      const int ib0 = max(i0, p.rc - p.H), ib1 = min(i0 + PM_TS - 1, p.rc + p.H);
-      a0 = ja0 - j0; na = ja1 - ja0 + 2;     // corners of columns ja0..ja1
-      b0 = ib0 - i0; nb = ib1 - ib0 + 2;     // corners of rows ib0..ib1
-      if (gt < na) {                // column edges a = a0 + gt: x of the lower edge of column j0+a
-        const int a = a0 + gt;
-        const double x = (j0 + a - p.cc) * c - c / 2;
-        const double h = (x - p.mux) / mp.sdx;
-        s_hx[g][a] = h;
-        s_px[g][a] = pm_phi(-h);
-      } else if (gt >= 64 && gt < 64 + nb) {   // row edges b: upper y edge of row i0+b
-        const int b = b0 + gt - 64;
-        const double y = (p.rc - (i0 + b)) * c + c / 2;
-        const double k = (y - p.muy) / mp.sdy;
-        s_ky[g][b] = k;
-        s_py[g][b] = pm_phi(-k);
-      }
+  const int N = mp.N;
+  PeriodInfo p;
+  int i0 = 0, j0 = 0, a0 = 0, na = 0, b0 = 0, nb = 0;
+  if (have) {
+    const int tl = pair_tile[pr];
+    const int d = d0 + tl / (nt * nt), rem = tl % (nt * nt);
+    i0 = (rem / nt) * PM_TS;
+    j0 = (rem % nt) * PM_TS;
+    p = pinfo[(int64_t)d * mp.T + pair_t[pr]];
+    // only the part of the tile under the stamp window needs corner values
+    const int ja0 = max(j0, p.cc - p.H), ja1 = min(j0 + PM_TS - 1, p.cc + p.H);
+    const int ib0 = max(i0, p.rc - p.H), ib1 = min(i0 + PM_TS - 1, p.rc + p.H);
+    a0 = ja0 - j0; na = ja1 - ja0 + 2;     // corners of columns ja0..ja1
+    b0 = ib0 - i0; nb = ib1 - ib0 + 2;     // corners of rows ib0..ib1
+    if (lane < na) {                 // column edges: x of the lower edge of column j0+a
+      const int a = a0 + lane;
+      const double x = (j0 + a - p.cc) * c - c / 2;
+      const double h = (x - p.mux) / mp.sdx;
+      s_hx[g][a] = h;
+      s_px[g][a] = pm_phi(-h);
+    } else if (lane >= 32 && lane < 32 + nb) {   // row edges: upper y edge of row i0+b
+      const int b = b0 + lane - 32;
+      const double y = (p.rc - (i0 + b)) * c + c / 2;
+      const double k = (y - p.muy) / mp.sdy;
+      s_ky[g][b] = k;
+      s_py[g][b] = pm_phi(-k);
     }
-    __syncthreads();
-    if (have && gt < na * nb) {
-      const int b = b0 + gt / na, a = a0 + gt % na;
+  }
+  __syncthreads();
+  if (have) {
+    for (int idx = lane; idx < na * nb; idx += 64) {
+      const int b = b0 + idx / na, a = a0 + idx % na;
       s_b[g][b * (PM_TS + 1) + a] = pm_bvu_phi(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
     }
-    __syncthreads();
-    if (have && gt < PM_TS * PM_TS) {
+  }
+  __syncthreads();
+  if (have) {
+    double* out = hm + pr * PM_CELLS;
+    for (int cell = lane; cell < PM_CELLS; cell += 64) {
+      const int li = cell / PM_TS, lj = cell % PM_TS;
       const int i = i0 + li, j = j0 + lj;
       const int ii = j - p.cc, jj = p.rc - i;
-      double hm = 0.0;    // +0.0 leaves the accumulator bit-identical when the cell is outside
+      double v = 0.0;    // +0.0 leaves the accumulator bit-identical when the cell is outside
       if (ii >= -p.H && ii <= p.H && jj >= -p.H && jj <= p.H && i < N && j < N) {
         // cell [xl,xu] x [yl,yu]: BVU(xl,yl) - BVU(xu,yl) - BVU(xl,yu) + BVU(xu,yu)
         const double ll = s_b[g][(li + 1) * (PM_TS + 1) + lj];
@@ -466,21 +498,26 @@ k_stamp_tiles(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInf
         const double lu = s_b[g][li * (PM_TS + 1) + lj];
         const double uu = s_b[g][li * (PM_TS + 1) + lj + 1];
         const double mass = ((ll - ul) - lu) + uu;
-        hm = __dmul_rn(p.hprob, mass);
+        v = __dmul_rn(p.hprob, mass);
       }
-      s_mass[g][gt] = hm;
+      out[cell] = v;
     }
-    __syncthreads();
-    if (tid < PM_TS * PM_TS) {
-      const int ng = min(PM_GROUPS, nlist - q0);
-      for (int k = 0; k < ng; ++k) acc = __dadd_rn(acc, s_mass[k][tid]);
-    }
-    // s_mass / s_b of this round are rewritten only after the next round's first barrier
   }
-  if (tid < PM_TS * PM_TS) {
-    const int i = i0 + tid / PM_TS, j = j0 + tid % PM_TS;
-    if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
-  }
+}
+
+// per tile: add the records of its pairs in list (= period) order
+__global__ void __launch_bounds__(PM_CELLS)
+k_tile_accumulate(ModelParams mp, const long long* __restrict__ tcnt, const long long* __restrict__ toff,
+                  int d0, long long base, const double* __restrict__ hm, double* pmf /*[nd][N][N]*/) {
+  const int d = d0 + blockIdx.z, N = mp.N;
+  const int64_t tile = ((int64_t)d * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const long long n = tcnt[tile];
+  if (n == 0) return;
+  const double* rec = hm + (toff[tile] - base) * PM_CELLS + threadIdx.x;
+  double acc = 0.0;
+  for (long long q = 0; q < n; ++q) acc = __dadd_rn(acc, rec[q * PM_CELLS]);
+  const int i = blockIdx.y * PM_TS + threadIdx.x / PM_TS, j = blockIdx.x * PM_TS + threadIdx.x % PM_TS;
+  if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
 }
 
 // sum and min of each day's pmf: partials per (day, block) then k_pmf_reduce2

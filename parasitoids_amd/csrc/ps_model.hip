@@ -21,7 +21,9 @@ struct ps_model {
   int nd = 0, N = 0, R = 0;
   DevBuf<int> day_idx;
   DevBuf<double> start_time, hprob, scratch, pmf, psum, pmin, rowsum;
-  DevBuf<long long> rowcnt, rowoff, doff;
+  DevBuf<long long> rowcnt, rowoff, doff, tcnt, toff;
+  DevBuf<int> pair_t, pair_tile;
+  DevBuf<double> hm;
   DevBuf<int> rowrad;
   DevBuf<PeriodInfo> pinfo;
   DevBuf<DayInfo> dinfo;
@@ -109,6 +111,7 @@ extern "C" int ps_model_destroy(ps_model* m) {
   m->wind.release(); m->day_keys.release(); m->day_idx.release(); m->start_time.release();
   m->hprob.release(); m->scratch.release(); m->pmf.release(); m->psum.release(); m->pmin.release();
   m->rowsum.release(); m->rowcnt.release(); m->rowoff.release(); m->doff.release(); m->rowrad.release();
+  m->tcnt.release(); m->toff.release(); m->pair_t.release(); m->pair_tile.release(); m->hm.release();
   m->pinfo.release(); m->dinfo.release(); m->orow.release(); m->ocol.release(); m->oval.release();
   m->stamp.release(); m->stampH.release();
   delete m;
@@ -190,10 +193,49 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
                      m->pinfo.p, m->dinfo.p, m->day_idx.p);
   PS_HIP(hipGetLastError());
   PS_HIP(hipMemsetAsync(m->pmf.p, 0, (size_t)nd * n2 * sizeof(double), st));
+  // stamp accumulation (model_kernels.h): ordered (tile, period) pair lists, one wave per pair
+  // for the masses, ordered per-tile accumulation; days are processed in chunks that keep the
+  // pair records (2 KB each) within ~2 GB
   const int nt = (N + PM_TS - 1) / PM_TS;
-  hipLaunchKernelGGL(k_stamp_tiles, dim3(nt, nt, nd), dim3(PM_TILE_THREADS), (size_t)T * sizeof(int), st, mp,
-                     m->pinfo.p, m->dinfo.p, m->pmf.p);
-  PS_HIP(hipGetLastError());
+  {
+    const int64_t ntl = (int64_t)nt * nt, ntot = ntl * nd;
+    PS_TRY(m->tcnt.ensure((size_t)ntot));
+    PS_TRY(m->toff.ensure((size_t)ntot));
+    hipLaunchKernelGGL(k_tile_count, dim3(nt, nt, nd), dim3(256), 0, st, mp, m->pinfo.p, m->dinfo.p, m->tcnt.p);
+    PS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, m->tcnt.p, (int)ntot, m->toff.p);
+    PS_HIP(hipGetLastError());
+    std::vector<long long> dayoff((size_t)nd + 1, 0);
+    long long last_cnt = 0;
+    for (int d = 0; d < nd; ++d)
+      PS_HIP(hipMemcpyAsync(&dayoff[(size_t)d], m->toff.p + (int64_t)d * ntl, sizeof(long long), hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(&dayoff[(size_t)nd], m->toff.p + (ntot - 1), sizeof(long long), hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(&last_cnt, m->tcnt.p + (ntot - 1), sizeof(long long), hipMemcpyDeviceToHost, st));
+    PS_HIP(hipStreamSynchronize(st));
+    dayoff[(size_t)nd] += last_cnt;
+    const long long max_pairs = (long long)1 << 20;   // 2 GB of records
+    int d0 = 0;
+    while (d0 < nd) {
+      int d1 = d0 + 1;
+      while (d1 < nd && dayoff[(size_t)d1 + 1] - dayoff[(size_t)d0] <= max_pairs) ++d1;
+      const long long base = dayoff[(size_t)d0], np = dayoff[(size_t)d1] - base;
+      if (np > 0) {
+        PS_TRY(m->pair_t.ensure((size_t)np));
+        PS_TRY(m->pair_tile.ensure((size_t)np));
+        PS_TRY(m->hm.ensure((size_t)np * PM_CELLS));
+        hipLaunchKernelGGL(k_tile_fill, dim3(nt, nt, d1 - d0), dim3(256), 0, st, mp, m->pinfo.p, m->dinfo.p, m->tcnt.p,
+                           m->toff.p, d0, base, m->pair_t.p, m->pair_tile.p);
+        PS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_pair_masses, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np,
+                           m->pair_t.p, m->pair_tile.p, m->hm.p);
+        PS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_tile_accumulate, dim3(nt, nt, d1 - d0), dim3(PM_CELLS), 0, st, mp, m->tcnt.p, m->toff.p, d0,
+                           base, m->hm.p, m->pmf.p);
+        PS_HIP(hipGetLastError());
+      }
+      d0 = d1;
+    }
+  }
   hipLaunchKernelGGL(k_pmf_reduce1, dim3(nblk, nd), dim3(256), 0, st, m->pmf.p, n2, m->psum.p, m->pmin.p);
   PS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_day_local, dim3(nd), dim3(256), 0, st, mp, m->psum.p, m->pmin.p, nblk, m->dinfo.p, m->pmf.p, 0);
