@@ -122,12 +122,14 @@ static __global__ void k_scan_rows(const long long* rowcnt_, int N, long long* r
   for (int r = lo; r < hi; ++r) s += rowcnt[r];
   part[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    long long acc = 0;
-    for (int t = 0; t < T; ++t) { long long v = part[t]; part[t] = acc; acc += v; }
+  // exclusive scan of the per-thread partial sums (integers: any order is exact)
+  for (int off = 1; off < T; off <<= 1) {
+    const long long v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
   }
-  __syncthreads();
-  long long acc = part[threadIdx.x];
+  long long acc = part[threadIdx.x] - s;
   for (int r = lo; r < hi; ++r) { rowoff[r] = acc; acc += rowcnt[r]; }
 }
 

@@ -171,20 +171,59 @@ __global__ void k_hprob(const double* __restrict__ wind, ModelParams mp, const i
     g[i] = 1.0 / (1. + exp(bw * (w[i * 3 + 2] - aw)));
   }
   __syncthreads();
-  __shared__ double s_max;
+  __shared__ double s_max, s_sum;
+  __shared__ double s_red[256];
   if (threadIdx.x == 0) {
-    // sequential like np.cumsum; numpy's pairwise .sum() differs by round-off only
-    double s = 0.0, mx = 0.0;
-    for (int i = 0; i < n; ++i) s += f[i];
-    for (int i = 0; i < n; ++i) {
-      f[i] = f[i] / s;
-      mx = fmax(mx, f[i]);
+    // sequential sum (numpy's pairwise .sum() differs by round-off only); eight LDS reads in
+    // flight per step, the additions in index order
+    double s = 0.0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = f[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; i < n; ++i) s += f[i];
+    s_sum = s;
+  }
+  __syncthreads();
+  {
+    // normalisation, its maximum and the integrand of the second cumulative sum are
+    // independent per sample: all threads
+    const double s = s_sum;
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const double fi = f[i] / s;
+      f[i] = fi;
+      mx = fmax(mx, fi);
+      c2[i] = fi - fi * g[i];
+    }
+    s_red[threadIdx.x] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0.0;
+    for (int t = 0; t < (int)blockDim.x; ++t) mx = fmax(mx, s_red[t]);
     s_max = mx;
+    // the two running sums, sequential like np.cumsum
     double c1 = 0.0, cc = 0.0;
-    for (int i = 0; i < n; ++i) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      double vf[8], vd[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { vf[u] = f[i + u]; vd[u] = c2[i + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        c1 += vf[u];
+        cc += (1 - c1) * vd[u];
+        c2[i + u] = cc;
+      }
+    }
+    for (; i < n; ++i) {
       c1 += f[i];
-      cc += (1 - c1) * (f[i] - f[i] * g[i]);
+      cc += (1 - c1) * c2[i];
       c2[i] = cc;
     }
   }
@@ -515,7 +554,15 @@ k_tile_accumulate(ModelParams mp, const long long* __restrict__ tcnt, const long
   if (n == 0) return;
   const double* rec = hm + (toff[tile] - base) * PM_CELLS + threadIdx.x;
   double acc = 0.0;
-  for (long long q = 0; q < n; ++q) acc = __dadd_rn(acc, rec[q * PM_CELLS]);
+  long long q = 0;
+  for (; q + 8 <= n; q += 8) {   // eight loads in flight, the additions stay in list order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = rec[(q + u) * PM_CELLS];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, v[u]);
+  }
+  for (; q < n; ++q) acc = __dadd_rn(acc, rec[q * PM_CELLS]);
   const int i = blockIdx.y * PM_TS + threadIdx.x / PM_TS, j = blockIdx.x * PM_TS + threadIdx.x % PM_TS;
   if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
 }

@@ -207,8 +207,9 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
     PS_HIP(hipGetLastError());
     std::vector<long long> dayoff((size_t)nd + 1, 0);
     long long last_cnt = 0;
-    for (int d = 0; d < nd; ++d)
-      PS_HIP(hipMemcpyAsync(&dayoff[(size_t)d], m->toff.p + (int64_t)d * ntl, sizeof(long long), hipMemcpyDeviceToHost, st));
+    // the first offset of every day in one strided copy
+    PS_HIP(hipMemcpy2DAsync(dayoff.data(), sizeof(long long), m->toff.p, (size_t)ntl * sizeof(long long),
+                            sizeof(long long), (size_t)nd, hipMemcpyDeviceToHost, st));
     PS_HIP(hipMemcpyAsync(&dayoff[(size_t)nd], m->toff.p + (ntot - 1), sizeof(long long), hipMemcpyDeviceToHost, st));
     PS_HIP(hipMemcpyAsync(&last_cnt, m->tcnt.p + (ntot - 1), sizeof(long long), hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
