@@ -554,13 +554,23 @@ k_tile_accumulate(ModelParams mp, const long long* __restrict__ tcnt, const long
   if (n == 0) return;
   const double* rec = hm + (toff[tile] - base) * PM_CELLS + threadIdx.x;
   double acc = 0.0;
+  // sixteen loads in flight while the previous sixteen are added; the additions stay in list order
   long long q = 0;
-  for (; q + 8 <= n; q += 8) {   // eight loads in flight, the additions stay in list order
-    double v[8];
+  double v[16];
+  const long long nfull = n / 16 * 16;
+  if (nfull > 0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = rec[(q + u) * PM_CELLS];
+    for (int u = 0; u < 16; ++u) v[u] = rec[u * PM_CELLS];
+  }
+  for (; q < nfull; q += 16) {
+    double w[16];
+    const bool more = q + 16 < nfull;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, v[u]);
+    for (int u = 0; u < 16; ++u) w[u] = more ? rec[(q + 16 + u) * PM_CELLS] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __dadd_rn(acc, v[u]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = w[u];
   }
   for (; q < n; ++q) acc = __dadd_rn(acc, rec[q * PM_CELLS]);
   const int i = blockIdx.y * PM_TS + threadIdx.x / PM_TS, j = blockIdx.x * PM_TS + threadIdx.x % PM_TS;

@@ -604,7 +604,10 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;
   }
-  s->L1 = ps_choose_col_split(s->Pf, 1200);
+  {
+    static const int single_max = getenv("PS_COL_SINGLE_MAX") ? atoi(getenv("PS_COL_SINGLE_MAX")) : 1200;   // tuning knob
+    s->L1 = ps_choose_col_split(s->Pf, single_max);
+  }
   if (const char* e = getenv("PS_COL_L1")) {   // tuning knob: first sub-pass length of the column split
     const int l1 = atoi(e);
     if (l1 > 1 && l1 < s->Pf && s->Pf % l1 == 0) s->L1 = l1;
