@@ -119,7 +119,17 @@ static __global__ void k_scan_rows(const long long* rowcnt_, int N, long long* r
   const int per = (N + T - 1) / T;
   const int lo = threadIdx.x * per, hi = min(N, lo + per);
   long long s = 0;
-  for (int r = lo; r < hi; ++r) s += rowcnt[r];
+  {
+    int r = lo;
+    for (; r + 8 <= hi; r += 8) {   // eight independent loads per step
+      long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = rowcnt[r + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < hi; ++r) s += rowcnt[r];
+  }
   part[threadIdx.x] = s;
   __syncthreads();
   // exclusive scan of the per-thread partial sums (integers: any order is exact)
@@ -130,7 +140,15 @@ static __global__ void k_scan_rows(const long long* rowcnt_, int N, long long* r
     __syncthreads();
   }
   long long acc = part[threadIdx.x] - s;
-  for (int r = lo; r < hi; ++r) { rowoff[r] = acc; acc += rowcnt[r]; }
+  int r = lo;
+  for (; r + 8 <= hi; r += 8) {
+    long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = rowcnt[r + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { rowoff[r + u] = acc; acc += v[u]; }
+  }
+  for (; r < hi; ++r) { rowoff[r] = acc; acc += rowcnt[r]; }
 }
 
 // ordered compaction: one wave per row, row-major COO order like coo_matrix(dense)
