@@ -157,3 +157,33 @@ def test_prob_mass_bad_parameters(PM, kalbar):
         PM.prob_mass(days[0], wd, HP, (-1.0, 1.0, 0.0), DLP, MU_R, NPER, 10000.0, 64)
     with pytest.raises(AssertionError):      # lam = 3 pushes hprob out of bounds
         PM.prob_mass(days[0], wd, (3.0,) + HP[1:], DP, DLP, MU_R, NPER, 10000.0, 64)
+
+
+def test_prob_mass_random_parameters_against_oracle(PM, kalbar, carnarvon):
+    '''Twelve random draws of the model parameters (flight/wind logistic parameters, diffusion
+    with correlations of both signs, mu_r, n_periods, grid resolution, start time) on random
+    days of both wind files against the oracle: identical COO pattern, values to 5e-15.'''
+    rng = np.random.default_rng(314159)
+    for case in range(12):
+        wd, days = kalbar if case % 2 == 0 else carnarvon
+        day = days[int(rng.integers(0, len(days) - 1))]
+        hp = (float(rng.uniform(0.6, 1.0)), float(rng.uniform(0.5, 2.5)), float(rng.uniform(2.0, 6.0)),
+              float(rng.uniform(5.0, 8.0)), float(rng.uniform(1.5, 4.0)), float(rng.uniform(18.0, 23.0)),
+              float(rng.uniform(1.5, 4.0)))
+        dp = (float(rng.uniform(80, 260)), float(rng.uniform(80, 220)), float(rng.uniform(-0.6, 0.6)))
+        dlp = (float(rng.uniform(3, 25)), float(rng.uniform(3, 25)), float(rng.uniform(-0.5, 0.5)))
+        mu_r = float(rng.uniform(0.6, 1.6))
+        npd = int(rng.integers(5, 50))
+        R = int(rng.integers(24, 64))
+        st = None if case % 3 else float(rng.uniform(0.1, 0.6))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            ref = OM.prob_mass(day, wd, hp, dp, dlp, mu_r, npd, 10000.0, R, st)
+            got = PM.prob_mass(day, wd, hp, dp, dlp, mu_r, npd, 10000.0, R, st)
+        msg = 'case %d day %d R=%d' % (case, day, R)
+        assert got.shape == ref.shape, msg
+        a, b = got.tocsr(), ref.tocsr()
+        a.sort_indices(); b.sort_indices()
+        assert a.nnz == b.nnz and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), msg
+        np.testing.assert_allclose(a.data, b.data, rtol=0, atol=VAL_ATOL, err_msg=msg)
+        assert abs(got.sum() - 1.0) < 1e-12

@@ -208,3 +208,50 @@ def test_flag_speculation_is_exact(hip_lib, monkeypatch):
             assert np.array_equal(a, b)
         if start != 150:
             assert any(flags) and not flags[0]      # the first flag falls inside a later window
+
+
+def test_random_small_chains_against_oracle(hip_lib):
+    '''Forty random small problems (domain 21..301, kernel shape 3..N, 2..5 days, kernels with
+    random support, sometimes mass leaving the domain) through the whole chain in exact mode
+    against the oracle: raw fields, flags, thresholded solutions.  Sizes are whatever the
+    random draw gives -- odd primes, powers of two plus one, pads with generic radices.'''
+    rng = np.random.default_rng(20260104)
+    checked_flags = 0
+    for case in range(40):
+        R = int(rng.integers(10, 151))
+        N = 2 * R + 1
+        K = 2 * int(rng.integers(1, min(R, 60) + 1)) + 1
+        nd = int(rng.integers(2, 6))
+        kernels = []
+        for _ in range(nd):
+            k = rng.random((K, K)) * (rng.random((K, K)) < rng.uniform(0.05, 0.6))
+            k[K // 2, K // 2] += 0.5
+            k /= k.sum()
+            kernels.append(sparse.coo_matrix(k))
+        npts = int(rng.integers(1, 6))
+        rows = rng.integers(0, N, npts); cols = rng.integers(0, N, npts)
+        vals = rng.random(npts); vals /= vals.sum()
+        state = sparse.coo_matrix((vals, (rows, cols)), shape=(N, N))
+        state.sum_duplicates()
+        ms = np.array([K, K])
+        P = N + K // 2
+        try:
+            s = hip_lib.HipSolve(state, ms, mode='exact')
+        except Exception as e:                      # prime factor > 1024 cannot happen below 400
+            raise AssertionError('P=%d not plannable: %s' % (P, e))
+        ref = [state]
+        trace = {}
+        OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, ms, trace=trace)
+        s.set_kernels(kernels)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        for d in range(nd):
+            np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13,
+                                       err_msg='case %d N=%d K=%d P=%d day %d' % (case, N, K, P, d))
+            # a pad maximum within round-off of the 1e-8 threshold may legitimately flip
+            assert bool(st[d].flag) == bool(trace['flags'][d]), (case, N, K, d)
+            got = s.chain_solution(d, st[d]).tocsr()
+            assert abs(got - ref[d + 1].tocsr()).max() < 1e-12
+        checked_flags += int(any(trace['flags']))
+        s.close()
+    assert checked_flags >= 5
