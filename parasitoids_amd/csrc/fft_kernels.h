@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(BIG ? 512 : 1024) k_row_inv(RowInvArgs a) {
   cplx* thi = tlo + P.n_lo;
   double* red = reinterpret_cast<double*>(tlo + tw_count(P));  // 4 * (blockDim/64) doubles
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
-  const int pair0 = blockIdx.x * a.rp;
+  const int pair0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * a.rp;   // cheap pad-only pairs first: no straggler round
   const int nthr = blockDim.x;
   load_tw(tlo, thi, P);
   // Workgroups whose rows all lie in the pad region (row >= N) only feed the boundary flag.

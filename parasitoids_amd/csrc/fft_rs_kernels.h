@@ -29,7 +29,10 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   constexpr int L = S::L;
   constexpr int NW = S::NTHR / 64;
   const int half = threadIdx.x / S::NTHR;
-  const int pair = blockIdx.x * NP + half;
+  // Reverse dispatch order: the cheap pad-only pairs (top rows, mostly skipped) and the odd
+  // last domain row go first, so the equally long domain workgroups that follow end together
+  // instead of leaving one straggler for an extra round.
+  const int pair = ((int)gridDim.x - 1 - (int)blockIdx.x) * NP + half;
   if (2 * pair >= a.P) return;   // ended waves do not take part in the barriers below
   double* ex = reinterpret_cast<double*>(ps_lds_raw) + half * (Y::XW + Y::RED);
   double* red = ex + Y::XW;      // 5 * NW doubles
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
   constexpr int L = S::L;
   if (pred_skip(a.pred)) return;
   const int half = threadIdx.x / S::NTHR;
-  const int pair = blockIdx.x * NP + half;
+  const int pair = ((int)gridDim.x - 1 - (int)blockIdx.x) * NP + half;   // cheap (dead) pairs first, see k_row_inv_rs
   const int ra = 2 * pair, rb = ra + 1;
   if (ra >= a.P) return;   // ended waves do not take part in the barriers below
   double* ex = reinterpret_cast<double*>(ps_lds_raw) + half * (Y::XW + Y::RED);
