@@ -66,7 +66,7 @@ def parse():
     ap.add_argument('--rad-res', type=int, default=2048, help='R; domain N = 2R+1')
     ap.add_argument('--kshape', type=int, default=2049)
     ap.add_argument('--ndays', type=int, default=30)
-    ap.add_argument('--mode', default='fast', choices=['fast', 'exact'])
+    ap.add_argument('--mode', default='fast', choices=['fast', 'exact', 'fold', 'auto'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-days', type=int, default=2)
     return ap.parse_args()
@@ -129,7 +129,7 @@ def main():
     state, kernels, params = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613)  # same stack on every rank
     N = 2 * R + 1
     P = N + K // 2
-    solver = hip_lib.HipSolve(state, [K, K], mode=args.mode, device=local)
+    solver = hip_lib.HipSolve(state, [K, K], mode=args.mode, device=local, chain_only=True)
     solver.set_kernels(kernels)
 
     def step():

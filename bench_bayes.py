@@ -71,7 +71,7 @@ def main():
     ap.add_argument('--evals', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rad-res', type=int, default=400)
-    ap.add_argument('--mode', default='auto', choices=['exact', 'fast', 'auto'])
+    ap.add_argument('--mode', default='auto', choices=['exact', 'fold', 'fast', 'auto'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))

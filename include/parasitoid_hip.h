@@ -37,6 +37,12 @@ extern "C" {
 
 #define PS_MODE_EXACT 0 /* FFT on the reference's torus P = N + K//2 (CalcSol.py:20-21) */
 #define PS_MODE_FAST 1  /* FFT on the next even 7-smooth size >= P                       */
+#define PS_MODE_FOLD 2  /* the reference's torus P, computed as a linear convolution on a fast
+                         * FFT size >= P + K - 1 and folded back modulo P: exact-torus semantics
+                         * at fast-size speed when P has large prime factors.  Chain API only
+                         * (set_state, set_kernels, chain_run, records); the per-call
+                         * fftconv2 / get_cursol / back_solve / spectrum calls return
+                         * PS_ERR_UNSUPPORTED. */
 
 typedef struct ps_solver ps_solver;
 typedef struct ps_model ps_model;

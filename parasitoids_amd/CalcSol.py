@@ -124,7 +124,7 @@ def get_solutions(modelsol, pmf_list, days, ndays, dom_len, max_shape):
     _need_device_backend()
     hip_lib = _hip()
     nk = len(days[1:ndays])
-    solver = hip_lib.HipSolve(modelsol[0], max_shape, mode=globalvars.fft_mode)
+    solver = hip_lib.HipSolve(modelsol[0], max_shape, mode=globalvars.fft_mode, chain_only=True)
     try:
         if solver.dom_len != dom_len:
             raise ValueError('dom_len {} != first solution {}'.format(dom_len, solver.dom_len))
@@ -150,7 +150,7 @@ def get_populations(r_spread, pmf_list, days, ndays, dom_len, max_shape,
     hip_lib = _hip()
     mid = dom_len // 2
     popmodel = []
-    solver = hip_lib.HipSolve(r_spread[0], max_shape, mode=globalvars.fft_mode)
+    solver = hip_lib.HipSolve(r_spread[0], max_shape, mode=globalvars.fft_mode, chain_only=(r_dur == 1))
     try:
         # first day: r_small_vals(r_spread[0]) * r_number * dist(1), rest still at the origin
         st = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)

@@ -27,6 +27,7 @@ PS_ERR_EMPTY = -11
 
 MODE_EXACT = 0
 MODE_FAST = 1
+MODE_FOLD = 2
 
 REC_CHAIN, REC_BACK, REC_STATE, REC_WSUM = 0, 1, 2, 3
 

@@ -110,6 +110,71 @@ static __global__ void k_row_stats(const double* __restrict__ rec, int N, double
   if (threadIdx.x == 0) { rowsum[r] = ssum[0]; rowcnt[r] = scnt[0]; }
 }
 
+// PS_MODE_FOLD: linear convolution result on the M-torus (index y in [-m, P+m), negative y at
+// M + y) -> circular result on the reference's P-torus: c[x] = lin[x] + lin[x+P] (x < m) +
+// lin[x-P] (x >= P-m) per dimension.  One block per torus row.  Writes the P x P torus field
+// (next day's state), the raw N x N record, the row statistics of r_small_vals
+// (CalcSol.py:126-135) and the maximum over the pad region (CalcSol.py:36-37).
+static __global__ void k_fold(const double* __restrict__ lin, int M, int P, int N, int m, double* torus,
+                              double* rec, double negval, double stat_scale, double* rowsum,
+                              long long* rowcnt, unsigned long long* padmax) {
+  const int r = blockIdx.x;
+  int yr[3], nr = 0;
+  yr[nr++] = r;
+  if (r < m) yr[nr++] = r + P;
+  if (r >= P - m) yr[nr++] = r - P + M;
+  __shared__ double ssum[256];
+  __shared__ long long scnt[256];
+  __shared__ double smax[256];
+  double s = 0.0, pm = 0.0;
+  long long cnt = 0;
+  for (int c = threadIdx.x; c < P; c += blockDim.x) {
+    int yc[3], nc = 0;
+    yc[nc++] = c;
+    if (c < m) yc[nc++] = c + P;
+    if (c >= P - m) yc[nc++] = c - P + M;
+    double v = 0.0;
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nc; ++j) v += lin[(int64_t)yr[i] * M + yc[j]];
+    torus[(int64_t)r * P + c] = v;
+    if (r < N && c < N) {
+      rec[(int64_t)r * N + c] = v;
+      const double t = v * stat_scale;
+      if (!(t < negval)) { s += t; ++cnt; }
+    } else {
+      pm = fmax(pm, v);
+    }
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = cnt;
+  smax[threadIdx.x] = pm;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + off];
+      scnt[threadIdx.x] += scnt[threadIdx.x + off];
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (r < N) { rowsum[r] = ssum[0]; rowcnt[r] = scnt[0]; }
+    const double mx = smax[0];
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+    if (mx > 0.0 && bits > __hip_atomic_load(padmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(padmax, bits);
+  }
+}
+
+// PS_MODE_FOLD: truncate the torus field to the domain when the day raised the flag
+// (CalcSol.py:200-201: the next transform starts from coo(A[:N,:N]))
+static __global__ void k_truncate_if_flag(double* torus, int P, int N, const unsigned long long* padmax) {
+  if (!(__longlong_as_double((long long)*padmax) > 1e-8)) return;
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < P; c += blockDim.x)
+    if (r >= N || c >= N) torus[(int64_t)r * P + c] = 0.0;
+}
+
 // exclusive scan of per-row counts (one block per record: blockIdx.x-th array of N counts)
 static __global__ void k_scan_rows(const long long* rowcnt_, int N, long long* rowoff_) {
   const long long* rowcnt = rowcnt_ + (int64_t)blockIdx.x * N;

@@ -182,6 +182,10 @@ struct ps_solver {
   DevBuf<const double*> wptr;
   DevBuf<double> wval;
   bool have_state = false;
+  // PS_MODE_FOLD: spatial state on the reference torus + linear-convolution scratch
+  DevBuf<double> torus, lin, fold_rowsum;
+  DevBuf<long long> fold_rowcnt;
+  DevBuf<unsigned long long> fold_padmax;
   // optional per-kernel-class HIP event timing (bench.py roofline leg)
   bool prof_on = false;
   struct ProfRec { int cls; hipEvent_t a, b; };
@@ -377,7 +381,7 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
 }
 
 static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_slot, int batch,
-                          double negval, double stat_scale) {
+                          double negval, double stat_scale, bool full_field = false) {
   RowInvArgs a;
   a.src = src; a.src_bstride = (int64_t)s->Pf * s->ld;
   a.H = s->H; a.ld = s->ld; a.P = s->Pf; a.N = s->N;
@@ -390,6 +394,12 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   a.rowcnt = s->rowcnt.p + (int64_t)stat_slot * s->N;
   a.padmax = s->padmax.p + stat_slot;
   a.stat_bstride = s->N;
+  if (full_field) {   // PS_MODE_FOLD: the whole Pf x Pf real field, statistics into scratch
+    a.N = s->Pf;
+    a.rec_bstride = (int64_t)s->Pf * s->Pf;
+    a.rowsum = s->fold_rowsum.p; a.rowcnt = s->fold_rowcnt.p; a.padmax = s->fold_padmax.p;
+    a.stat_bstride = s->Pf;
+  }
   const int npairs = (s->Pf + 1) / 2;
   dim3 grid((npairs + a.rp - 1) / a.rp, batch);
   const int thr = row_threads(a.prog.L, s->row_big);
@@ -566,7 +576,7 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   if (!out) return ps_fail(PS_ERR_BAD_ARG, "null output handle");
   *out = nullptr;
   if (dom_len < 1 || max_shape < 1) return ps_fail(PS_ERR_BAD_SHAPE, "dom_len=%d max_shape=%d", dom_len, max_shape);
-  if (mode != PS_MODE_EXACT && mode != PS_MODE_FAST) return ps_fail(PS_ERR_BAD_ARG, "mode %d", mode);
+  if (mode != PS_MODE_EXACT && mode != PS_MODE_FAST && mode != PS_MODE_FOLD) return ps_fail(PS_ERR_BAD_ARG, "mode %d", mode);
   PS_TRY(ps_use_device(device));
   PS_TRY(set_lds_attr());
   ps_solver* s = new ps_solver();
@@ -576,6 +586,8 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   s->Pref = dom_len + s->M;  // CalcSol.py:20-21, cuda_lib.py:26-28
   s->mode = mode;
   s->Pf = mode == PS_MODE_FAST ? fast_size(s->Pref) : s->Pref;
+  // fold mode: room for the whole linear convolution, P + K - 1 = N + 3 (K//2)
+  if (mode == PS_MODE_FOLD) s->Pf = fast_size(s->Pref + 2 * s->M);
   s->H = s->Pf / 2 + 1;
   s->ld = (s->H + 7) & ~7;
   auto fail = [&](int rc) {
@@ -677,6 +689,7 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   for (auto e : s->spec_ev) if (e) (void)hipEventDestroy(e);
   if (s->hflags) (void)hipHostFree(s->hflags);
   s->dkoff.release(); s->dkshape.release();
+  s->torus.release(); s->lin.release(); s->fold_rowsum.release(); s->fold_rowcnt.release(); s->fold_padmax.release();
   delete s;
   return PS_OK;
 }
@@ -742,6 +755,14 @@ int ps_solver_set_state_device_coo(ps_solver* s, const int* row, const int* col,
   double* rec = s->recs[PS_REC_STATE][0];
   PS_HIP(hipMemsetAsync(rec, 0, (size_t)s->N * s->N * sizeof(double), s->stream));
   PS_TRY(scatter_from_device(s, row, col, val, nnz, rec, s->N, off));
+  if (s->mode == PS_MODE_FOLD) {   // the state lives in space, on the reference torus
+    PS_TRY(s->torus.ensure((size_t)s->Pref * s->Pref));
+    PS_HIP(hipMemsetAsync(s->torus.p, 0, (size_t)s->Pref * s->Pref * sizeof(double), s->stream));
+    PS_HIP(hipMemcpy2DAsync(s->torus.p, (size_t)s->Pref * sizeof(double), rec, (size_t)s->N * sizeof(double),
+                            (size_t)s->N * sizeof(double), (size_t)s->N, hipMemcpyDeviceToDevice, s->stream));
+    s->have_state = true;
+    return PS_OK;
+  }
   PS_TRY(fwd2d(s, rec, 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), s->Ahat.p, 1, nullptr));
   s->have_state = true;
   return PS_OK;
@@ -895,6 +916,44 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
   PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
   s->last_renorm = renorm;
+  if (s->mode == PS_MODE_FOLD) {
+    // Per day: transform the torus field (zero-padded to the FFT size), multiply with the day
+    // kernel's spectrum inside the fused column pass, invert to the full linear-convolution
+    // field, fold it back modulo P (k_fold: next state, record, statistics, pad maximum) and
+    // drop the pad region if the day raised the flag.  Same results as the direct transform on
+    // the reference torus up to round-off, on fast FFT sizes.
+    const size_t spec = (size_t)s->Pf * s->ld;
+    PS_TRY(s->Ahat.ensure(spec));
+    PS_TRY(s->lin.ensure((size_t)s->Pf * s->Pf));
+    PS_TRY(s->fold_rowsum.ensure((size_t)s->Pf));
+    PS_TRY(s->fold_rowcnt.ensure((size_t)s->Pf));
+    PS_TRY(s->fold_padmax.ensure(1));
+    PS_TRY(ensure_temps(s, 1));
+    for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
+      const int cn = std::min(s->chunk_days, first + count - c0);
+      PS_TRY(transform_kernels(s, c0, cn));
+      for (int d = c0; d < c0 + cn; ++d) {
+        const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
+        PS_TRY(fwd2d(s, s->torus.p, 0, s->Pref, map_plain(s->Pref, s->Pf), map_plain(s->Pref, s->Pf),
+                     s->Ahat.p, 1, nullptr));
+        PS_TRY(launch_col_fused(s, B, s->Ahat.p, 0, s->T1.p, s->krange.p + 2 * d));
+        if (s->split) {
+          PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
+          PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
+        } else {
+          PS_TRY(launch_row_inv(s, s->T1.p, s->lin.p, d, 1, negval, stat_scale, true));
+        }
+        hipLaunchKernelGGL(k_fold, dim3(s->Pref), dim3(256), 0, s->stream, s->lin.p, s->Pf, s->Pref, s->N, s->M,
+                           s->torus.p, s->recs[PS_REC_CHAIN][d], negval, stat_scale,
+                           s->rowsum.p + (int64_t)d * s->N, s->rowcnt.p + (int64_t)d * s->N, s->padmax.p + d);
+        PS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_truncate_if_flag, dim3(s->Pref), dim3(256), 0, s->stream, s->torus.p, s->Pref, s->N,
+                           s->padmax.p + d);
+        PS_HIP(hipGetLastError());
+      }
+    }
+    return PS_OK;
+  }
   s->spec_window = 1;
   if (getenv("PS_NO_SPECULATION")) s->speculate = false;
   if (s->speculate) {
@@ -988,6 +1047,7 @@ __global__ void k_cmul_inplace(cplx* a, const cplx* b, int64_t n) {
 extern "C" int ps_solver_fftconv2_coo(ps_solver* s, const int32_t* row, const int32_t* col,
                                       const double* val, int64_t nnz, int kshape) {
   if (!s || nnz < 0) return ps_fail(PS_ERR_BAD_ARG, "fftconv2: bad arguments");
+  if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "fftconv2: PS_MODE_FOLD offers the chain API only");
   if (!s->have_state) return ps_fail(PS_ERR_STATE, "fftconv2 before set_state");
   if (kshape < 1 || kshape % 2 == 0) return ps_fail(PS_ERR_BAD_SHAPE, "kernel shape %d must be odd (CalcSol.py:58)", kshape);
   if (kshape > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "kernel shape %d larger than the pad %d", kshape, s->Pf);
@@ -1011,6 +1071,7 @@ extern "C" int ps_solver_fftconv2_coo(ps_solver* s, const int32_t* row, const in
 extern "C" int ps_solver_get_cursol(ps_solver* s, double negval, double stat_scale, int renorm,
                                     ps_day_stats* stats) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "get_cursol: PS_MODE_FOLD offers the chain API only");
   if (!s->have_state) return ps_fail(PS_ERR_STATE, "get_cursol before set_state");
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(ensure_record(s, PS_REC_CHAIN, 0));
@@ -1028,6 +1089,7 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
                                     const int32_t* col, const double* val, double negval,
                                     double stat_scale, ps_day_stats* stats) {
   if (!s || nfilt < 0 || !off) return ps_fail(PS_ERR_BAD_ARG, "back_solve: bad arguments");
+  if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "back_solve: PS_MODE_FOLD offers the chain API only");
   if (!s->have_state) return ps_fail(PS_ERR_STATE, "back_solve before set_state");
   if (s->N % 2 == 0) return ps_fail(PS_ERR_BAD_SHAPE, "back_solve needs an odd domain (filters are N x N)");
   if (2 * (s->N / 2) + 1 > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "filter larger than the pad");
@@ -1205,6 +1267,7 @@ extern "C" int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const i
 // ----------------------------------------------------------------- spectrum
 extern "C" int ps_solver_get_spectrum(ps_solver* s, double* out) {
   if (!s || !out) return ps_fail(PS_ERR_BAD_ARG, "get_spectrum: bad arguments");
+  if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "get_spectrum: PS_MODE_FOLD offers the chain API only");
   if (!s->have_state) return ps_fail(PS_ERR_STATE, "get_spectrum before set_state");
   PS_HIP(hipSetDevice(s->device));
   const size_t full = (size_t)s->Pf * s->Pf;
@@ -1221,6 +1284,7 @@ extern "C" int ps_solver_get_spectrum(ps_solver* s, double* out) {
 
 extern "C" int ps_solver_set_spectrum(ps_solver* s, const double* in) {
   if (!s || !in) return ps_fail(PS_ERR_BAD_ARG, "set_spectrum: bad arguments");
+  if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "set_spectrum: PS_MODE_FOLD offers the chain API only");
   PS_HIP(hipSetDevice(s->device));
   const size_t full = (size_t)s->Pf * s->Pf;
   DevBuf<cplx> tmp;

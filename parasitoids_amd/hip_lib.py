@@ -23,34 +23,55 @@ def _coo_arrays(A):
     return L.i32(A.row), L.i32(A.col), L.f64(A.data), A.shape
 
 
-def _create_solver(lib, handle, dev, dom_len, max_shape, mode):
-    """ps_solver_create with mode 'exact' | 'fast' | 'auto' (exact when the reference's pad
-    size can be planned -- every prime factor <= 1024 -- else the 7-smooth fast size).
+def _smooth7(n):
+    for p in (2, 3, 5, 7):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+def _create_solver(lib, handle, dev, dom_len, max_shape, mode, chain_only=False):
+    """ps_solver_create with mode
+      'exact'  transform on the reference's pad P = N + K//2 itself (any P whose prime factors
+               are <= 1024);
+      'fold'   the same torus, computed as a linear convolution on a fast FFT size >= P + K - 1
+               and folded back modulo P -- chain API only;
+      'fast'   a convenient FFT size >= P (pad-region dust lives on a different torus);
+      'auto'   exact when P is 7-smooth (cheap), else fold when the caller only needs the chain
+               API (`chain_only`), else exact; fast if none of them can be planned.
     Returns the mode actually used."""
-    if mode not in ('exact', 'fast', 'auto'):
-        raise ValueError("mode must be 'exact', 'fast' or 'auto'")
-    if mode != 'fast':
-        rc = lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, L.MODE_EXACT)
+    if mode not in ('exact', 'fold', 'fast', 'auto'):
+        raise ValueError("mode must be 'exact', 'fold', 'fast' or 'auto'")
+    order = {'exact': ['exact'], 'fold': ['fold'], 'fast': ['fast']}.get(mode)
+    if order is None:
+        P = dom_len + max_shape // 2
+        if _smooth7(P) or not chain_only:
+            order = ['exact', 'fast']
+        else:
+            order = ['fold', 'exact', 'fast']
+    code = {'exact': L.MODE_EXACT, 'fold': L.MODE_FOLD, 'fast': L.MODE_FAST}
+    rc = L.PS_OK
+    for m in order:
+        rc = lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, code[m])
         if rc == L.PS_OK:
-            return 'exact'
-        if mode == 'exact' or rc != L.PS_ERR_UNSUPPORTED:
-            L.check(rc)
-    L.check(lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, L.MODE_FAST))
-    return 'fast'
+            return m
+        if rc != L.PS_ERR_UNSUPPORTED:
+            break
+    L.check(rc)
 
 
 class HipSolve():
     """Device-resident Fourier-space solution, cf. `cuda_lib.CudaSolve`."""
 
-    def __init__(self, A, max_shape, mode='exact', device=None):
+    def __init__(self, A, max_shape, mode='exact', device=None, chain_only=False):
         '''Initialize the solver with the fft of the solution after the first day.
 
         Args:
             A: First day's spread, sparse matrix (square, N x N)
             max_shape: Shape of the largest filter (cuda_lib.py:18-28)
-            mode: 'exact' transforms on the reference's pad P = N + max_shape//2;
-                  'fast' on the next even 7-smooth size >= P; 'auto' = exact when P can be
-                  planned (prime factors <= 1024), else fast'''
+            mode: 'exact' | 'fold' | 'fast' | 'auto', see `_create_solver`
+            chain_only: the caller uses set_kernels / run_chain / records only (lets 'auto'
+                  pick the fold mode, which has no per-call fftconv2 / get_cursol / back_solve)'''
         self._h = L._VP()
         self._lib = L.load()
         row, col, val, shape = _coo_arrays(A)
@@ -65,7 +86,7 @@ class HipSolve():
         mmid = ms // 2
         self.pad_shape = (int(shape[0] + mmid[0]), int(shape[1] + mmid[1]))
         dev = L.default_device() if device is None else device
-        self.mode = _create_solver(self._lib, self._h, dev, self.dom_len, int(ms[0]), mode)
+        self.mode = _create_solver(self._lib, self._h, dev, self.dom_len, int(ms[0]), mode, chain_only)
         info = [C.c_int32() for _ in range(4)]
         L.check(self._lib.ps_solver_info(self._h, *[C.byref(v) for v in info]))
         self.fft_len = info[2].value
@@ -74,7 +95,7 @@ class HipSolve():
         self._nk = 0
 
     @classmethod
-    def from_model(cls, model, i, max_shape, mode='exact', device=None):
+    def from_model(cls, model, i, max_shape, mode='exact', device=None, chain_only=False):
         '''Solver whose first-day state is day i of `model`'s last device batch, re-centred
         into the domain (Run.py:454-458) without leaving the GPU.'''
         self = cls.__new__(cls)
@@ -85,7 +106,7 @@ class HipSolve():
         self.dom_len = N
         self.pad_shape = (N + ms // 2, N + ms // 2)
         dev = L.default_device() if device is None else device
-        self.mode = _create_solver(self._lib, self._h, dev, N, ms, mode)
+        self.mode = _create_solver(self._lib, self._h, dev, N, ms, mode, chain_only)
         info = [C.c_int32() for _ in range(4)]
         L.check(self._lib.ps_solver_info(self._h, *[C.byref(v) for v in info]))
         self.fft_len = info[2].value

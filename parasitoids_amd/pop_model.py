@@ -64,7 +64,7 @@ class PopModel():
             if len(self._solvers) >= self._max_solvers:
                 self._solvers.pop(next(iter(self._solvers))).close()
             s = self._hip.HipSolve.from_model(self.model, 0, [key, key], mode=self.mode,
-                                              device=self.device)
+                                              device=self.device, chain_only=True)
         else:
             s.set_state_from_model(self.model, 0)
         self._solvers[key] = s          # most recently used last

@@ -50,7 +50,7 @@ def main():
     res = PM.prob_mass_batch(days[:2], wd, HP, DP, DLP, MU_R, NPER, 10000.0, 400)
     e = max(np.abs(r.data - g5['kal400_d%d_val' % d]).max() for d, r in zip(days[:2], res))
     line('prob_mass Kalbar R=400, 2 days: values', e, 5e-15)
-    for R, mode in ((128, 'exact'), (200, 'exact'), (200, 'fast')):
+    for R, mode in ((128, 'exact'), (200, 'exact'), (200, 'fold'), (200, 'fast')):
         tag = 'r%d' % R
         nd = int(g6[tag + '_ndays'])
         pmfs = [coo_from(g6, '%s_pmf%d' % (tag, i)) for i in range(nd)]
@@ -66,8 +66,8 @@ def main():
         e = max(np.abs(s.dense(0, n) - trace['raw'][n]).max() for n in range(nd - 1))
         flags_ok = [bool(x.flag) for x in st] == [bool(f) for f in g6[tag + '_flags']]
         line('get_solutions R=%d %d days, %s (P=%d, FFT %d): raw states; flags identical: %s'
-             % (R, nd, mode, s.pad_shape[0], s.fft_len, flags_ok), e, 1e-12 if mode == 'exact' else 5e-8)
-        if mode == 'exact':
+             % (R, nd, mode, s.pad_shape[0], s.fft_len, flags_ok), e, 5e-8 if mode == 'fast' else 1e-12)
+        if mode != 'fast':
             e = max(abs(s.chain_solution(n, st[n]).tocsr() - ref[n + 1].tocsr()).max() for n in range(nd - 1))
             line('   ... thresholded + renormalised solutions vs reference', e, 1e-12)
         s.close()

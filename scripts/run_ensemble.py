@@ -36,7 +36,7 @@ def main():
     ap.add_argument('--members', type=int, default=512)
     ap.add_argument('--rad-res', type=int, default=1024)
     ap.add_argument('--ndays', type=int, default=30)
-    ap.add_argument('--mode', default='fast', choices=['auto', 'exact', 'fast'])
+    ap.add_argument('--mode', default='fast', choices=['auto', 'exact', 'fold', 'fast'])
     args = ap.parse_args()
     warnings.simplefilter('ignore', RuntimeWarning)
     from parasitoids_amd import parallel, ParasitoidModel as PM

@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--samples', type=int, default=200)
     ap.add_argument('--burn', type=int, default=20)
     ap.add_argument('--rad-res', type=int, default=400)
-    ap.add_argument('--mode', default='auto', choices=['exact', 'fast', 'auto'])
+    ap.add_argument('--mode', default='auto', choices=['exact', 'fold', 'fast', 'auto'])
     ap.add_argument('--seed', type=int, default=1000)
     ap.add_argument('--synthetic', action='store_true',
                     help='observations drawn from the model on a Kalbar-like geometry instead of '

@@ -71,7 +71,8 @@ def test_spectrum_roundtrip(hip_lib, two_arrays):
     np.testing.assert_allclose(solver.get_spectrum(), ref, rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize('R,mode', [(128, 'exact'), (200, 'exact'), (128, 'fast'), (200, 'fast')])
+@pytest.mark.parametrize('R,mode', [(128, 'exact'), (200, 'exact'), (128, 'fast'), (200, 'fast'),
+                                    (128, 'fold'), (200, 'fold')])
 def test_get_solutions_chain(hip_lib, golden, R, mode):
     '''G6: CalcSol.get_solutions on Kalbar kernels.  R=128: P=364=4*7*13 (no flags);
     R=200: P=573=3*191 (generic radix, flags fire on 16 of 17 days).'''
@@ -89,17 +90,20 @@ def test_get_solutions_chain(hip_lib, golden, R, mode):
 
     solver = hip_lib.HipSolve(first, ms, mode=mode)
     assert solver.pad_shape == (N + ms[0] // 2, N + ms[1] // 2)
+    if mode == 'fold':       # linear convolution on a fast size, folded back onto the reference torus
+        assert solver.fft_len >= N + 3 * (ms[0] // 2) and solver.mode == 'fold'
     solver.set_kernels(pmfs[1:])
     solver.run_chain(0, nd - 1, negval=1e-8, scale=1.0, renorm=True)
     stats = solver.chain_stats(0, nd - 1)
-    tol = ATOL if mode == 'exact' else 5e-8   # fast mode: pad-region semantics differ
+    exact = mode in ('exact', 'fold')         # both on the reference torus
+    tol = ATOL if exact else 5e-8             # fast mode: pad-region semantics differ
     pos = g[tag + '_pos']
     for n in range(nd - 1):
         raw = solver.dense(0, n)
         np.testing.assert_allclose(raw, trace['raw'][n], rtol=0, atol=tol)
         np.testing.assert_allclose(raw[pos[:, 0], pos[:, 1]], g['%s_rawsamp%d' % (tag, n + 1)],
                                    rtol=0, atol=tol)
-        if mode == 'exact':
+        if exact:
             assert bool(stats[n].flag) == bool(g[tag + '_flags'][n])
             sol = solver.chain_solution(n, stats[n])
             assert_summary(g, '%s_sum%d' % (tag, n + 1), sol, pos, rtol=1e-11, atol=1e-12,
@@ -235,23 +239,20 @@ def test_random_small_chains_against_oracle(hip_lib):
         state.sum_duplicates()
         ms = np.array([K, K])
         P = N + K // 2
-        try:
-            s = hip_lib.HipSolve(state, ms, mode='exact')
-        except Exception as e:                      # prime factor > 1024 cannot happen below 400
-            raise AssertionError('P=%d not plannable: %s' % (P, e))
         ref = [state]
         trace = {}
         OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, ms, trace=trace)
-        s.set_kernels(kernels)
-        s.run_chain(renorm=True)
-        st = s.chain_stats(0, nd)
-        for d in range(nd):
-            np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13,
-                                       err_msg='case %d N=%d K=%d P=%d day %d' % (case, N, K, P, d))
-            # a pad maximum within round-off of the 1e-8 threshold may legitimately flip
-            assert bool(st[d].flag) == bool(trace['flags'][d]), (case, N, K, d)
-            got = s.chain_solution(d, st[d]).tocsr()
-            assert abs(got - ref[d + 1].tocsr()).max() < 1e-12
+        for mode in ('exact', 'fold'):            # direct transform on P / linear convolution folded onto P
+            s = hip_lib.HipSolve(state, ms, mode=mode)
+            s.set_kernels(kernels)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            for d in range(nd):
+                np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13,
+                                           err_msg='%s case %d N=%d K=%d P=%d day %d' % (mode, case, N, K, P, d))
+                assert bool(st[d].flag) == bool(trace['flags'][d]), (mode, case, N, K, d)
+                got = s.chain_solution(d, st[d]).tocsr()
+                assert abs(got - ref[d + 1].tocsr()).max() < 1e-12
+            s.close()
         checked_flags += int(any(trace['flags']))
-        s.close()
     assert checked_flags >= 5
