@@ -71,6 +71,11 @@ int ps_solver_create(ps_solver** out, int device, int dom_len, int max_shape, in
 /* FFT size a PS_MODE_FAST solver would use for this domain and kernel shape (no device needed):
  * lets a caller size max_shape so that one solver serves a range of kernel shapes. */
 int ps_fast_size(int dom_len, int max_shape);
+/* PS_MODE_FOLD only: change the kernel shape limit (and with it the reference torus
+ * P = N + max_shape/2) of an existing solver, keeping its FFT size, plans and buffers -- valid
+ * while N + 3 (max_shape/2) fits the solver's FFT size (ps_solver_info).  The state has to be
+ * set again afterwards. */
+int ps_solver_retarget(ps_solver* s, int max_shape);
 int ps_solver_destroy(ps_solver* s);
 /* P = reference torus, Pfft = transform size in use, H = Pfft/2+1 */
 int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H);

@@ -68,6 +68,7 @@ SIGNATURES = {
     'ps_chain_stats': (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(DayStats)]),
     'ps_record_stats': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.POINTER(DayStats)]),
+    'ps_solver_retarget': (C.c_int, [_VP, C.c_int]),
     'ps_fast_size': (C.c_int, [C.c_int, C.c_int]),
     'ps_record_fetch_coo': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                       C.c_double, _I32P, _I32P, _F64P, C.c_int64, _I64P]),

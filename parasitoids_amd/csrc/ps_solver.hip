@@ -694,6 +694,23 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   return PS_OK;
 }
 
+extern "C" int ps_solver_retarget(ps_solver* s, int max_shape) {
+  if (!s || max_shape < 1) return ps_fail(PS_ERR_BAD_ARG, "retarget: bad arguments");
+  if (s->mode != PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "retarget: only PS_MODE_FOLD solvers can change their torus");
+  const int m = max_shape / 2;
+  if (s->N + 3 * m > s->Pf)
+    return ps_fail(PS_ERR_BAD_SHAPE, "retarget: max_shape %d needs an FFT size >= %d, the solver has %d", max_shape,
+                   s->N + 3 * m, s->Pf);
+  PS_HIP(hipSetDevice(s->device));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  s->M = m;
+  s->Pref = s->N + m;
+  s->have_state = false;
+  s->bhat_first = -1;
+  s->bhat_count = 0;
+  return PS_OK;
+}
+
 extern "C" int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
   if (dom_len) *dom_len = s->N;

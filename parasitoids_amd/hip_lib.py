@@ -114,6 +114,14 @@ class HipSolve():
         self.set_state_from_model(model, i)
         return self
 
+    def retarget(self, max_shape):
+        '''fold mode: move the solver to another kernel shape limit / reference torus, keeping
+        its FFT size, plans and buffers (the state has to be set again)'''
+        ms = int(np.array(max_shape).ravel()[0])
+        L.check(self._lib.ps_solver_retarget(self._h, ms))
+        self.pad_shape = (self.dom_len + ms // 2, self.dom_len + ms // 2)
+        self._nk = 0
+
     def set_state_from_model(self, model, i):
         L.check(self._lib.ps_solver_set_state_from_model(self._h, model._h, int(i)))
 

@@ -60,6 +60,16 @@ class PopModel():
             if fits:
                 key = min(fits)
         s = self._solvers.pop(key, None)
+        if s is None and self.mode in ('auto', 'fold'):
+            # a cached fold-mode solver whose FFT size has room for this torus is re-targeted
+            # (same plans and buffers) instead of building a new one for every kernel shape
+            need = N + 3 * (key // 2)
+            for k in list(self._solvers):
+                c = self._solvers[k]
+                if c.mode == 'fold' and need <= c.fft_len <= 1.15 * need:
+                    s = self._solvers.pop(k)
+                    s.retarget(key)
+                    break
         if s is None:
             if len(self._solvers) >= self._max_solvers:
                 self._solvers.pop(next(iter(self._solvers))).close()
