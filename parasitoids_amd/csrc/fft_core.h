@@ -326,6 +326,43 @@ PS_HD void bfly_pfa(cplx* x) {
   }
 }
 
+// radix 25 = 5 x 5 (not coprime: Cooley-Tukey with the twiddles w25^(q0 k1))
+template <int DIR>
+PS_HD void bfly25(cplx* x) {
+  // q = q0 + 5 q1 ; y_{k1 + 5 k0} = sum_q0 w25^(q0 k1) (sum_q1 x w5^(q1 k1)) w5^(q0 k0)
+  const double c[17] = {1.0, 0.96858316112863108, 0.87630668004386358, 0.72896862742141155,
+                        0.53582679497899666, 0.30901699437494742, 0.062790519529313374,
+                        -0.18738131458572463, -0.42577929156507272, -0.63742398974868975,
+                        -0.80901699437494742, -0.92977648588825146, -0.99211470131447788,
+                        -0.99211470131447788, -0.92977648588825146, -0.80901699437494742,
+                        -0.63742398974868975};
+  const double sn[17] = {0.0, 0.24868988716485479, 0.48175367410171532, 0.68454710592868873,
+                         0.84432792550201508, 0.95105651629515357, 0.99802672842827156,
+                         0.98228725072868872, 0.90482705246601958, 0.77051324277578925,
+                         0.58778525229247313, 0.36812455268467797, 0.12533323356430426,
+                         -0.12533323356430426, -0.36812455268467797, -0.58778525229247313,
+                         -0.77051324277578925};
+  const double sg = DIR == PS_FWD ? -1.0 : 1.0;
+  cplx u[5][5];
+#pragma unroll
+  for (int q0 = 0; q0 < 5; ++q0) {
+    cplx t[5] = {x[q0], x[q0 + 5], x[q0 + 10], x[q0 + 15], x[q0 + 20]};
+    bfly_odd<5, DIR>(t);
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1) {
+      const int e = q0 * k1;   // <= 16
+      u[q0][k1] = e == 0 ? t[k1] : cmul(t[k1], make_double2(c[e], sg * sn[e]));
+    }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    cplx t[5] = {u[0][k1], u[1][k1], u[2][k1], u[3][k1], u[4][k1]};
+    bfly_odd<5, DIR>(t);
+#pragma unroll
+    for (int k0 = 0; k0 < 5; ++k0) x[k1 + 5 * k0] = t[k0];
+  }
+}
+
 template <int R, int DIR>
 PS_HD void bfly(cplx* x) {
   if (R == 2) bfly2<DIR>(x);
@@ -342,6 +379,7 @@ PS_HD void bfly(cplx* x) {
   else if (R == 16) bfly16<DIR>(x);
   else if (R == 18) bfly18<DIR>(x);
   else if (R == 20) bfly_pfa<4, 5, DIR>(x);
+  else if (R == 25) bfly25<DIR>(x);
 }
 
 // ------------------------------------------------------------------ twiddles

@@ -65,9 +65,9 @@ PS_HD void rs_get(const double* ex, int base, int stride, cplx* x) {
 // chained products per twiddle and ~30 live registers instead of a full w[R] array.
 template <int R, int DIR>
 PS_HD void rs_stage(cplx* x, cplx w1, bool tw) {
-  static_assert(R <= 20, "twiddle generation covers q < 20");
+  static_assert(R <= 28, "twiddle generation covers q < 28");
   if (tw) {
-    cplx lo[4], hi[5];
+    cplx lo[4], hi[7];
     lo[1] = w1;
     lo[2] = cmul(w1, w1);
     lo[3] = cmul(lo[2], w1);
@@ -75,6 +75,10 @@ PS_HD void rs_stage(cplx* x, cplx w1, bool tw) {
     hi[2] = cmul(hi[1], hi[1]);
     hi[3] = cmul(hi[2], hi[1]);
     hi[4] = cmul(hi[2], hi[2]);
+    if (R > 20) {
+      hi[5] = cmul(hi[4], hi[1]);
+      hi[6] = cmul(hi[3], hi[3]);
+    }
 #pragma unroll
     for (int q = 1; q < R; ++q) {
       const int a = q >> 2, b = q & 3;

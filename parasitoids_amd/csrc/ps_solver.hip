@@ -561,7 +561,8 @@ static int fast_size(int Pref) {
   int Pf = ps_next_fast_len(Pref);
   if (getenv("PS_NO_RS") == nullptr) {
     const int L = rs_next_size(Pref);
-    if (L > 0 && (double)L * L <= 1.08 * (double)Pf * Pf) Pf = L;
+    // ... or whenever the 7-smooth size is beyond the LDS-resident row limit (~9700)
+    if (L > 0 && ((double)L * L <= 1.08 * (double)Pf * Pf || Pf > 9700)) Pf = L;
   }
   return Pf;
 }
@@ -607,8 +608,12 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   if (!s->row_big && !ps_build_plan(s->Pf, true, &s->row_plan.host))
     return fail(ps_fail(PS_ERR_UNSUPPORTED, "cannot plan a length-%d FFT (prime factor > %d); use PS_MODE_FAST",
                         s->Pf, PS_MAX_GENERIC_RADIX));
-  if ((size_t)(row_pitch(s->row_plan.host.prog) + 512) * sizeof(cplx) > (size_t)kMaxLds)
-    return fail(ps_fail(PS_ERR_UNSUPPORTED, "pad size %d exceeds the LDS-resident row limit", s->Pf));
+  {
+    int r2 = 0, r3 = 0;
+    const bool rs = getenv("PS_NO_RS") == nullptr && rs_lookup(s->Pf, &r2, &r3);   // rows stay in registers
+    if (!rs && (size_t)(row_pitch(s->row_plan.host.prog) + 512) * sizeof(cplx) > (size_t)kMaxLds)
+      return fail(ps_fail(PS_ERR_UNSUPPORTED, "pad size %d exceeds the LDS-resident row limit", s->Pf));
+  }
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
   if (getenv("PS_NO_RS") == nullptr && !rs_lookup(s->Pf, &s->rs_r2, &s->rs_r3)) s->rs_r2 = s->rs_r3 = 0;

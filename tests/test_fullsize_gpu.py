@@ -158,7 +158,8 @@ def test_chain_with_flags_at_awkward_sizes(hip_lib, R, K, mode):
                                     (800, 601, 4),      # 1920 = 16*12*10 (prime-factor radices)
                                     (1400, 1101, 3),    # 3360 = 16*15*14
                                     (2048, 3201, 2),    # 5760 = 16*20*18
-                                    (2600, 2299, 2)])   # 6400 = 16*20*20
+                                    (2600, 2299, 2),    # 6400 = 16*20*20
+                                    (2900, 2737, 2)])   # 7200 = 16*25*18 (radix 25)
 def test_register_resident_row_kernels_match_lds_kernels(hip_lib, monkeypatch, R, K, nd):
     '''fft_rs.h kernels (sizes 1296, 2592, 5184: forward and inverse rows, incl. the re-FFT of
     flagged days) against the LDS-resident program on the same fast size: same flags, fields
@@ -175,7 +176,7 @@ def test_register_resident_row_kernels_match_lds_kernels(hip_lib, monkeypatch, R
         else:
             monkeypatch.setenv('PS_NO_RS', '1')
         s = hip_lib.HipSolve(state, [K, K], mode='fast')
-        assert s.fft_len in (1296, 2592, 5184, 1920, 3360, 5760, 6400)
+        assert s.fft_len in (1296, 2592, 5184, 1920, 3360, 5760, 6400, 7200)
         out.append(s.fft_len)
         s.set_kernels(kernels)
         s.run_chain(renorm=True)
@@ -235,16 +236,27 @@ def test_every_register_resident_size(hip_lib, monkeypatch):
                 monkeypatch.delenv('PS_NO_RS', raising=False)
             else:
                 monkeypatch.setenv('PS_NO_RS', '1')
-            s = hip_lib.HipSolve(state, [K, K], mode='fast')
+            try:
+                s = hip_lib.HipSolve(state, [K, K], mode='fast')
+            except L.HipError as e:
+                assert not rs and e.code == L.PS_ERR_UNSUPPORTED and Lfft > 9700   # beyond the LDS-resident rows
+                res.append(None)
+                continue
             assert s.fft_len == Lfft
             s.set_kernels(kernels)
             s.run_chain(renorm=True)
             st = s.chain_stats(0, 2)
             res.append(([s.dense(0, d) for d in range(2)], [bool(x.flag) for x in st]))
             s.close()
-        assert res[0][1] == res[1][1], Lfft
-        for a, b in zip(res[0][0], res[1][0]):
-            np.testing.assert_allclose(a, b, rtol=0, atol=1e-14, err_msg=str(Lfft))
+        if res[0] is None:
+            # no LDS-resident program at this size: invariants of the transform instead
+            for f in res[1][0]:
+                assert f.min() > -1e-13 and 0.3 < f.sum() <= 1.0 + 1e-12
+            assert any(res[1][1])
+        else:
+            assert res[0][1] == res[1][1], Lfft
+            for a, b in zip(res[0][0], res[1][0]):
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-14, err_msg=str(Lfft))
         done += 1
     monkeypatch.delenv('PS_NO_RS', raising=False)
     assert done >= 35
