@@ -223,6 +223,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(state, kernels, K, args.cpu_days)
+            if args.mode == 'fast':
+                # for reference: the same stack with exact reference-torus results ('auto' mode:
+                # direct transform on P, or the folded linear convolution when P is awkward)
+                solver.close()
+                s2 = hip_lib.HipSolve(state, [K, K], mode='auto', device=local, chain_only=True)
+                s2.set_kernels(kernels)
+                for i in range(3):
+                    if i == 1:
+                        s2.sync(); t1 = time.perf_counter()
+                    s2.set_state(state)
+                    s2.run_chain(0, nd, negval=1e-8, scale=1.0, renorm=True)
+                s2.sync()
+                out['exact_torus_mode'] = {'value': round(2 * nd / (time.perf_counter() - t1), 3),
+                                           'unit': 'grid-days/s', 'mode': s2.mode, 'fft_len': s2.fft_len}
+                s2.close()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
