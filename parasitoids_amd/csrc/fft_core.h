@@ -401,7 +401,7 @@ PS_HD int ps_div(int x, uint32_t mg) {
 
 // ------------------------------------------------------ butterfly addressing
 // mode COL: LDS holds a [L][W] tile (W = 1 << wsh columns, the batch), FFT along
-//           the rows; lanes run along the batch.
+//           the rows; lanes run along the batch.  bs != 0: row pitch 1 << bs instead of W.
 // mode ROW: LDS holds nb padded rows; lanes run along whichever digit is
 //           contiguous (leading stages) or along the La padded sub-rows
 //           (trailing stages), so both are bank-conflict free.
@@ -420,8 +420,9 @@ PS_HD BfAddr bf_decode(const FftProg& P, int s, int mode, int item, int wsh, int
     const int bf = item >> wsh;
     const int blk = ps_div(bf, P.mg_m[s]);
     const int j = bf - blk * m;
-    a.addr0 = ((blk * n + j) << wsh) + b;
-    a.qstride = m << wsh;
+    const int psh = bs ? bs : wsh;  // COL mode: bs != 0 gives the tile's row pitch (log2)
+    a.addr0 = ((blk * n + j) << psh) + b;
+    a.qstride = m << psh;
     a.j = j;
   } else {
     const int nbf = m * (P.L / n);

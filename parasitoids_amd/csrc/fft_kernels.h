@@ -375,6 +375,7 @@ struct ColFusedArgs {
   int64_t src_bstride;
   int ld, ncols, wsh, L1, L2, store_prod;
   RowLive live;      // kernel rows known to be zero are not read
+  RowLive live2;     // DUAL: state rows known to be zero
   FftProg prog;      // length L2
 };
 
@@ -441,6 +442,66 @@ __global__ void k_col_fused(ColFusedArgs a) {
   for (int idx = threadIdx.x; idx < tot; idx += nthr) {
     const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
     if (col < a.ncols) a.dst[(base + row) * a.ld + col] = data[idx];
+  }
+}
+
+// PS_MODE_FOLD variant: the state arrives like the kernel, one column sub-pass short of its
+// spectrum (it is re-transformed from space every day).  Kernel tile and state tile sit side by
+// side in one [L x 2W] LDS tile, ONE forward FFT finishes both, the product goes into the left
+// half, the inverse sub-pass follows -- the state's last forward
+// sub-pass never touches HBM.  `state` is read-only here, same row layout as `src`.
+template <bool GEN>
+__global__ void k_col_fused_dual(ColFusedArgs a) {
+  const FftProg& P = a.prog;
+  const int L = P.L;
+  const int W = 1 << a.wsh, wsh2 = a.wsh + 1;
+  cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
+  cplx* tlo = data + ((size_t)L << wsh2);
+  cplx* thi = tlo + P.n_lo;
+  const int ntiles = (a.ncols + W - 1) >> a.wsh;
+  const int tile = blockIdx.x % ntiles;
+  const int o = blockIdx.x / ntiles;
+  const int c0 = tile << a.wsh;
+  const int nthr = blockDim.x;
+  load_tw(tlo, thi, P);
+  const int tot = L << a.wsh;
+  const int64_t base = (int64_t)o * a.L2;
+  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+    cplx v[PS_UNROLL], w[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
+      v[u] = make_double2(0.0, 0.0);
+      w[u] = v[u];
+      if (idx < tot && col < a.ncols) {
+        if (row_live(a.live, (int)(base + row), 0)) v[u] = a.src[(base + row) * a.ld + col];
+        if (row_live(a.live2, (int)(base + row), 0)) w[u] = a.state[(base + row) * a.ld + col];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      if (idx < tot) {
+        const int row = idx >> a.wsh, c = idx & (W - 1);
+        data[(row << wsh2) + c] = v[u];
+        data[(row << wsh2) + W + c] = w[u];
+      }
+    }
+  }
+  __syncthreads();
+  lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, 2 * W, wsh2, 0);
+  // product of the two halves (same LDS row = same spectral index) into the left half, which
+  // the inverse sub-pass then transforms at the tile's pitch of 2W
+  for (int idx = threadIdx.x; idx < tot; idx += nthr) {
+    const int e = ((idx >> a.wsh) << wsh2) + (idx & (W - 1));
+    data[e] = cmul(data[e], data[e + W]);
+  }
+  __syncthreads();
+  lds_fft<PS_INV, GEN>(data, tlo, thi, P, PS_MODE_COL, W, a.wsh, wsh2);
+  for (int idx = threadIdx.x; idx < tot; idx += nthr) {
+    const int row = idx >> a.wsh, c = idx & (W - 1), col = c0 + c;
+    if (col < a.ncols) a.dst[(base + row) * a.ld + col] = data[(row << wsh2) + c];
   }
 }
 

@@ -503,6 +503,44 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   return PS_OK;
 }
 
+// PS_MODE_FOLD: kernel and state both one column sub-pass short of their spectra
+// (k_col_fused_dual).  *done = 0 when the double-width tile does not fit in LDS: the caller
+// takes the separate-pass route.
+static int launch_col_fused_dual(ps_solver* s, const cplx* kt, const cplx* state_part, RowLive state_live,
+                                 cplx* dst, const int* rowrange, int* done) {
+  ColFusedArgs a;
+  DevPlan* plan = s->split ? &s->col_plan2 : &s->col_plan1;
+  a.src = kt; a.state = const_cast<cplx*>(state_part); a.dst = dst;
+  a.src_bstride = 0;
+  a.ld = s->ld; a.ncols = s->H;
+  a.L1 = s->split ? s->L1 : 1;
+  a.L2 = s->split ? s->L2 : s->Pf;
+  a.store_prod = 0;
+  a.live = s->kt_live;
+  a.live.range = rowrange;
+  a.live2 = state_live;
+  a.prog = plan->prog;
+  a.wsh = std::min(col_wsh(a.prog.L), 4);
+  if (const char* e = getenv("PS_DUAL_WSH")) a.wsh = atoi(e);   // tuning knob
+  auto need = [&](int wsh) {
+    return (((size_t)a.prog.L << (wsh + 1)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
+  };
+  while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
+  *done = 0;
+  if (need(a.wsh) > (size_t)kMaxLds || getenv("PS_NO_DUAL")) return PS_OK;
+  const int W = 1 << a.wsh;
+  dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
+  ProfScope prof(s, PS_PROF_COL_INV_A);
+  static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
+  if (plan->generic)
+    hipLaunchKernelGGL(k_col_fused_dual<true>, grid, dim3(fthr), need(a.wsh), s->stream, a);
+  else
+    hipLaunchKernelGGL(k_col_fused_dual<false>, grid, dim3(fthr), need(a.wsh), s->stream, a);
+  PS_HIP(hipGetLastError());
+  *done = 1;
+  return PS_OK;
+}
+
 // one day step: state_hat <- state_hat * K_hat (stored when store_prod), rec <- ifft2(...)
 static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, double* rec,
                     int stat_slot, double negval, double stat_scale, const int* rowrange = nullptr) {
@@ -951,19 +989,37 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     PS_TRY(s->fold_rowcnt.ensure((size_t)s->Pf));
     PS_TRY(s->fold_padmax.ensure(1));
     PS_TRY(ensure_temps(s, 1));
+    PS_TRY(s->T2.ensure(spec));
     for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
       const int cn = std::min(s->chunk_days, first + count - c0);
       PS_TRY(transform_kernels(s, c0, cn));
       for (int d = c0; d < c0 + cn; ++d) {
         const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
-        PS_TRY(fwd2d(s, s->torus.p, 0, s->Pref, map_plain(s->Pref, s->Pf), map_plain(s->Pref, s->Pf),
-                     s->Ahat.p, 1, nullptr));
-        PS_TRY(launch_col_fused(s, B, s->Ahat.p, 0, s->T1.p, s->krange.p + 2 * d));
+        const SrcMap tmap = map_plain(s->Pref, s->Pf);
+        // state: row pass (+ first column sub-pass); its last forward sub-pass runs inside the
+        // fused kernel next to the kernel's
+        PS_TRY(launch_row_fwd(s, s->torus.p, 0, s->Pref, tmap, tmap, s->T1.p, 1, nullptr, 1));
+        const cplx* part = s->T1.p;
+        cplx* fused_out = s->T2.p;
+        RowLive part_live{1, tmap, nullptr};
+        if (s->split) {
+          PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr, part_live));
+          part = s->T2.p;
+          fused_out = s->T1.p;
+          part_live = RowLive{0, {0, 0, 0, 0}, nullptr};
+        }
+        int dual = 0;
+        PS_TRY(launch_col_fused_dual(s, B, part, part_live, fused_out, s->krange.p + 2 * d, &dual));
+        if (!dual) {  // finish the state's spectrum, then the ordinary fused pass
+          const ColPass& last = s->fwd_passes.back();
+          PS_TRY(launch_col<PS_FWD>(s, last, part, nullptr, nullptr, s->Ahat.p, 1, 0, nullptr, part_live));
+          PS_TRY(launch_col_fused(s, B, s->Ahat.p, 0, fused_out, s->krange.p + 2 * d));
+        }
         if (s->split) {
           PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
           PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
         } else {
-          PS_TRY(launch_row_inv(s, s->T1.p, s->lin.p, d, 1, negval, stat_scale, true));
+          PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
         }
         hipLaunchKernelGGL(k_fold, dim3(s->Pref), dim3(256), 0, s->stream, s->lin.p, s->Pf, s->Pref, s->N, s->M,
                            s->torus.p, s->recs[PS_REC_CHAIN][d], negval, stat_scale,
