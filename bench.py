@@ -34,9 +34,16 @@ ALG_P2 = {
     'col_inv_b': 8.0,    # inverse column sub-pass 2
     'row_inv': 24.0,     # inverse C2R row pass (16) + epilogue read of the real field (8)
     'refft_pred': 0.0,   # flag-conditional re-FFT launches (40 P^2 per flagged day; no-ops here)
+    # the fused pass over 2/4/8 consecutive days in one launch: col_inv_a's 40 P^2 per grid-day
+    # x the days one launch processes (the launch itself moves fewer bytes -- the intermediate
+    # state spectra stay in LDS -- which is what `traffic` shows)
+    'col_inv_a_x2': 80.0, 'col_inv_a_x4': 160.0, 'col_inv_a_x8': 320.0,
 }
+DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8}
 # kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
-PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1'}
+PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1',
+            'col_inv_a_x2': 'void k_col_fused_multi<false, 2>', 'col_inv_a_x4': 'void k_col_fused_multi<false, 4>',
+            'col_inv_a_x8': 'void k_col_fused_multi<false, 8>'}
 
 
 def pmc_traffic(kernel_class):
@@ -44,7 +51,9 @@ def pmc_traffic(kernel_class):
     summary (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE);
     None when no summary covers the kernel."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_pmc.json')))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_pmc.json')),
+                   key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])   # r01_v10 after r01_v9
     name = PMC_NAME.get(kernel_class)
     if not files or name is None:
         return None, None
@@ -198,7 +207,9 @@ def main():
             print(json.dumps({'value': round(value, 3), 'ms_per_step': round(dt / args.steps * 1e3, 3),
                               'note': 'HIP-event profiling disabled'}))
             return
-        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches'])
+        # total time per class: multi-day launches are all timed, the others every PROF_EVERY-th
+        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches']
+                  * (1 if k in DAYS_PER_LAUNCH else PROF_EVERY))
         ach = kern[dom]['alg_GBps']
         traffic, traffic_src = pmc_traffic(dom) if (R, K, nd) == (2048, 2049, 30) else (None, None)
         out = {

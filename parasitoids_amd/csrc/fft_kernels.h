@@ -373,6 +373,7 @@ struct ColFusedArgs {
   cplx* state;       // A_hat, read; overwritten with the product when store_prod
   cplx* dst;
   int64_t src_bstride;
+  int64_t dst_dstride; // MULTI: distance between the days' outputs
   int ld, ncols, wsh, L1, L2, store_prod;
   RowLive live;      // kernel rows known to be zero are not read
   RowLive live2;     // DUAL: state rows known to be zero
@@ -442,6 +443,86 @@ __global__ void k_col_fused(ColFusedArgs a) {
   for (int idx = threadIdx.x; idx < tot; idx += nthr) {
     const int row = idx >> a.wsh, col = c0 + (idx & (W - 1));
     if (col < a.ncols) a.dst[(base + row) * a.ld + col] = data[idx];
+  }
+}
+
+// ND consecutive days in one pass (ND = 2, 4 or 8): the kernels of days d .. d+ND-1 sit side by
+// side in one [L x ND*W] LDS tile, ONE forward FFT finishes all of them, the state is chained
+// through them (A_{d+1} = A_d K_d, A_{d+2} = A_{d+1} K_{d+1}, ... -- the same products in the
+// same order as ND single-day passes, so the results are bit-identical), only the LAST
+// spectrum goes back to HBM, one inverse FFT, ND outputs.  HBM traffic per day drops from 4
+// spectra to (2 + 2 ND) / ND.  Valid while no day in the group raises the boundary flag: the
+// caller only groups days inside a speculation window (ps_chain_run).
+template <bool GEN, int ND>
+__global__ void k_col_fused_multi(ColFusedArgs a) {
+  constexpr int NDSH = ND == 2 ? 1 : (ND == 4 ? 2 : 3);
+  static_assert(ND == 2 || ND == 4 || ND == 8, "ND must be 2, 4 or 8");
+  const FftProg& P = a.prog;
+  const int L = P.L;
+  const int W = 1 << a.wsh, wshn = a.wsh + NDSH, WN = W << NDSH;
+  cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
+  cplx* tlo = data + ((size_t)L << wshn);
+  cplx* thi = tlo + P.n_lo;
+  int* spos = reinterpret_cast<int*>(thi + P.n_hi + P.n_gen);
+  const int ntiles = (a.ncols + W - 1) >> a.wsh;
+  const int tile = blockIdx.x % ntiles;
+  const int o = blockIdx.x / ntiles;
+  const int c0 = tile << a.wsh;
+  const int nthr = blockDim.x;
+  load_tw(tlo, thi, P);
+  for (int r = threadIdx.x; r < L; r += nthr) spos[r] = (int)P.pos[r];
+  const int tot = L << a.wsh, totn = L << wshn;
+  const int64_t base = (int64_t)o * a.L2;
+  for (int idx0 = threadIdx.x; idx0 < totn; idx0 += nthr * PS_UNROLL) {
+    cplx v[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      const int row = idx >> wshn, cc = idx & (WN - 1);
+      const int day = cc >> a.wsh, col = c0 + (cc & (W - 1));
+      v[u] = make_double2(0.0, 0.0);
+      if (idx < totn && col < a.ncols && row_live(a.live, (int)(base + row), day))
+        v[u] = a.src[day * a.src_bstride + (base + row) * a.ld + col];
+    }
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      if (idx < totn) data[idx] = v[u];
+    }
+  }
+  __syncthreads();
+  lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, WN, wshn, 0);
+  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+    cplx v[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      const int k = idx >> a.wsh, col = c0 + (idx & (W - 1));
+      v[u] = make_double2(0.0, 0.0);
+      if (idx < tot && col < a.ncols) v[u] = a.state[((int64_t)o + (int64_t)a.L1 * k) * a.ld + col];
+    }
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const int idx = idx0 + u * nthr;
+      if (idx >= tot) continue;
+      const int k = idx >> a.wsh, c = idx & (W - 1);
+      const int l = (spos[k] << wshn) + c;
+      cplx x = v[u];
+#pragma unroll
+      for (int day = 0; day < ND; ++day) {
+        x = cmul(x, data[l + (day << a.wsh)]);
+        data[l + (day << a.wsh)] = x;
+      }
+      if (a.store_prod && c0 + c < a.ncols)
+        a.state[((int64_t)o + (int64_t)a.L1 * k) * a.ld + c0 + c] = x;
+    }
+  }
+  __syncthreads();
+  lds_fft<PS_INV, GEN>(data, tlo, thi, P, PS_MODE_COL, WN, wshn, 0);
+  for (int idx = threadIdx.x; idx < totn; idx += nthr) {
+    const int row = idx >> wshn, cc = idx & (WN - 1);
+    const int day = cc >> a.wsh, col = c0 + (cc & (W - 1));
+    if (col < a.ncols) a.dst[day * a.dst_dstride + (base + row) * a.ld + col] = data[idx];
   }
 }
 

@@ -120,9 +120,10 @@ void ps_dev_free(void* p) {
 
 void ps_dev_quiesce() { (void)hipDeviceSynchronize(); }
 static const int kPredGrid = 512;  // grid of the flag-conditional (usually empty) launches
-#define PS_PROF_NCLS 8
+#define PS_PROF_NCLS 10
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
-       PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6 };
+       PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6, PS_PROF_COL_INV_A2 = 7,
+       PS_PROF_COL_INV_A4 = 8, PS_PROF_COL_INV_A8 = 9 };
 
 struct ColPass {
   DevPlan* plan;
@@ -140,6 +141,7 @@ struct ps_solver {
   int num_cu = 256;
   // flag speculation in ps_chain_run: on until this solver has seen a boundary flag
   bool speculate = true;
+  int fused_days = getenv("PS_FUSED_DAYS") ? atoi(getenv("PS_FUSED_DAYS")) : 8;   // days per fused column pass (1, 2, 4, 8)
   int spec_window = 1;
   hipEvent_t spec_ev[2] = {nullptr, nullptr};
   unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
@@ -213,7 +215,8 @@ struct ProfScope {
   bool on;
   ProfScope(ps_solver* s_, int cls) : s(s_), on(false) {
     if (!s->prof_on) return;
-    on = (s->prof_seen[cls]++ % s->prof_every) == 0;
+    // the few multi-day launches are all timed; the others every prof_every-th per class
+    on = cls >= PS_PROF_COL_INV_A2 || (s->prof_seen[cls]++ % s->prof_every) == 0;
     if (!on) return;
     r.cls = cls;
     r.a = prof_event(s);
@@ -503,6 +506,50 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   return PS_OK;
 }
 
+// nd (2, 4 or 8) consecutive days in one fused pass (k_col_fused_multi): kernels at kt + i*spec,
+// outputs at dst + i*spec.  *done = 0 when the wider tile does not fit in LDS.
+static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, cplx* dst,
+                                  const int* rowrange, int* done) {
+  ColFusedArgs a;
+  DevPlan* plan = s->split ? &s->col_plan2 : &s->col_plan1;
+  const int64_t spec = (int64_t)s->Pf * s->ld;
+  a.src = kt; a.state = state; a.dst = dst;
+  a.src_bstride = spec;
+  a.dst_dstride = spec;
+  a.ld = s->ld; a.ncols = s->H;
+  a.L1 = s->split ? s->L1 : 1;
+  a.L2 = s->split ? s->L2 : s->Pf;
+  a.store_prod = 1;
+  a.live = s->kt_live;
+  a.live.range = rowrange;
+  a.live2 = RowLive{0, {0, 0, 0, 0}, nullptr};
+  a.prog = plan->prog;
+  const int ndsh = nd == 2 ? 1 : (nd == 4 ? 2 : 3);
+  // 8-column tiles for four or more days: 37 KB of LDS per workgroup keeps four of them on a CU
+  a.wsh = std::min(col_wsh(a.prog.L), nd >= 4 ? 3 : 4);
+  if (const char* e = getenv("PS_MULTI_WSH")) a.wsh = atoi(e);   // tuning knob
+  auto need = [&](int wsh) {
+    return (((size_t)a.prog.L << (wsh + ndsh)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+  };
+  while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
+  *done = 0;
+  if (need(a.wsh) > (size_t)kMaxLds) return PS_OK;
+  const int W = 1 << a.wsh;
+  dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
+  ProfScope prof(s, nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4 : PS_PROF_COL_INV_A8);
+  static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
+#define PS_MULTI_LAUNCH(ND)                                                                                   \
+  if (plan->generic) hipLaunchKernelGGL((k_col_fused_multi<true, ND>), grid, dim3(fthr), need(a.wsh), s->stream, a); \
+  else hipLaunchKernelGGL((k_col_fused_multi<false, ND>), grid, dim3(fthr), need(a.wsh), s->stream, a)
+  if (nd == 2) { PS_MULTI_LAUNCH(2); }
+  else if (nd == 4) { PS_MULTI_LAUNCH(4); }
+  else { PS_MULTI_LAUNCH(8); }
+#undef PS_MULTI_LAUNCH
+  PS_HIP(hipGetLastError());
+  *done = 1;
+  return PS_OK;
+}
+
 // PS_MODE_FOLD: kernel and state both one column sub-pass short of their spectra
 // (k_col_fused_dual).  *done = 0 when the double-width tile does not fit in LDS: the caller
 // takes the separate-pass route.
@@ -548,6 +595,24 @@ static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, d
   if (!s->split) return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
   PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
   return launch_row_inv(s, s->T2.p, rec, stat_slot, 1, negval, stat_scale);
+}
+
+// nd un-flagged day steps with one fused pass; recs/stat slots of days d0 .. d0+nd-1
+static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, double* const* recs, int d0,
+                          double negval, double stat_scale, const int* rowrange, int* done) {
+  const size_t spec = (size_t)s->Pf * s->ld;
+  PS_TRY(s->T1.ensure(spec * nd));
+  PS_TRY(launch_col_fused_multi(s, kt, nd, state, s->T1.p, rowrange, done));
+  if (!*done) return PS_OK;
+  for (int i = 0; i < nd; ++i) {
+    cplx* t = s->T1.p + i * spec;
+    if (s->split) {
+      PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], t, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
+      t = s->T2.p;
+    }
+    PS_TRY(launch_row_inv(s, t, recs[i], d0 + i, 1, negval, stat_scale));
+  }
+  return PS_OK;
 }
 
 static SrcMap map_plain(int n, int P) { return SrcMap{n, 0, P, 0}; }
@@ -1032,7 +1097,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     }
     return PS_OK;
   }
-  s->spec_window = 1;
+  s->spec_window = 2;   // 2 + 4 + 8 = one chunk of 14 days, all of them in multi-day fused passes
   if (getenv("PS_NO_SPECULATION")) s->speculate = false;
   if (s->speculate) {
     for (int i = 0; i < 2; ++i)
@@ -1062,7 +1127,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     // the check.  No flag: the days stand as they are (the conditional launches would have
     // returned at once).  First flag at day f: its truncated field is re-transformed for
     // real, every day after f -- computed from a spectrum the reference would have replaced
-    // -- is redone, and this solver stops speculating.  Windows grow 1, 2, 4, ... so an
+    // -- is redone, and this solver stops speculating.  Windows grow 2, 4, 8, ... so an
     // early flag wastes little.
     struct Win { int d0, w, ev; };
     std::deque<Win> q;
@@ -1075,7 +1140,23 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       static const size_t depth = getenv("PS_SPEC_DEPTH") ? (size_t)atoi(getenv("PS_SPEC_DEPTH")) : 2;
       while (q.size() < depth && d < c0 + cn) {
         const int w = std::min(s->spec_window, c0 + cn - d);
-        for (int i = 0; i < w; ++i) PS_TRY(day(d + i, false));
+        // inside a window no flag is expected: days go through the fused pass in groups
+        for (int i = 0; i < w;) {
+          int g = 0;
+          if (s->fused_days > 1 && w - i >= 2) {
+            const int nd = (s->fused_days >= 8 && w - i >= 8) ? 8 : (s->fused_days >= 4 && w - i >= 4) ? 4 : 2;
+            const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
+            PS_TRY(conv_inv_multi(s, B, nd, s->Ahat.p, &s->recs[PS_REC_CHAIN][d + i], d + i, negval, stat_scale,
+                                  s->krange.p + 2 * (d + i), &g));
+            if (g) g = nd;
+            else s->fused_days = 1;   // tile does not fit: single days from here on
+          }
+          if (!g) {
+            PS_TRY(day(d + i, false));
+            g = 1;
+          }
+          i += g;
+        }
         PS_HIP(hipMemcpyAsync(s->hflags + d, s->padmax.p + d, (size_t)w * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, s->stream));
         PS_HIP(hipEventRecord(s->spec_ev[nev & 1], s->stream));

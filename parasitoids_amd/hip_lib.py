@@ -263,7 +263,7 @@ class HipSolve():
         L.check(self._lib.ps_solver_sync(self._h))
 
     PROF_CLASSES = ('row_fwd', 'col_fwd_a', 'col_fwd_b', 'col_inv_a', 'col_inv_b', 'row_inv',
-                    'refft_pred')
+                    'refft_pred', 'col_inv_a_x2', 'col_inv_a_x4', 'col_inv_a_x8')
 
     def prof_enable(self, on=True, every=1):
         '''HIP-event timing per kernel class on the solver's stream; `every` = n times only
