@@ -377,8 +377,135 @@ struct ColFusedArgs {
   int ld, ncols, wsh, L1, L2, store_prod;
   RowLive live;      // kernel rows known to be zero are not read
   RowLive live2;     // DUAL: state rows known to be zero
+  // direct != 0 (split columns, sparse day kernels): `src` is the ROW-pass output and the
+  // kernel's first column sub-pass is evaluated as a direct sum over its few live rows
+  // (kt_direct_fill); tp_* = two-level twiddle table of w_N, N = L1 L2; mgL2 = ps_magic(L2)
+  int direct;
+  const cplx* tp_lo;
+  const cplx* tp_hi;
+  int tp_shift;
+  uint32_t mgL2;
   FftProg prog;      // length L2
 };
+
+// First column sub-pass of a sparse day kernel without the HBM round trip.  With row index
+// n = i + L2 j (i < L2, j < L1) the sub-pass output the fused kernels consume is
+//   Y[o L2 + i] = w_N^{i o} * sum_j R[i + L2 j] w_L1^{j o}            (R = row-pass output),
+// an L1-point DFT per i of which only the live rows (the kernel's support, two intervals of
+// the wrapped K x K box: RowLive) are non-zero -- a handful of terms per i for the compact
+// kernels prob_mass produces.  The sums are evaluated right where the tile is needed, so the
+// intermediate spectrum (one write + one read of P^2/2 complex per day) never exists and the
+// separate k_col launch disappears; the live rows are re-read by every o, out of L2.
+// Fills data[(i << psh) + (day << wsh) + c]; stw[i] = w_N^{i o}, wj[j] = w_L1^{j o} in LDS.
+__device__ __forceinline__ void kt_direct_tables(const ColFusedArgs& a, cplx* stw, cplx* wj, int o) {
+  for (int r = threadIdx.x; r < a.L2; r += blockDim.x) stw[r] = tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, o * r);
+  for (int j = threadIdx.x; j < a.L1; j += blockDim.x)
+    wj[j] = tw_lookup(a.tp_lo, a.tp_hi, a.tp_shift, ((j * o) % a.L1) * a.L2);
+}
+// G outer indices o .. o+G-1 per workgroup share every row load: column group (g * ND + day)
+// of the tile, tables stw[g * L2 + i], wj[g * L1 + j]
+template <int G>
+__device__ __forceinline__ void kt_direct_fill(const ColFusedArgs& a, cplx* data, const cplx* stw, const cplx* wj,
+                                               int c0, int psh, int ndsh) {
+  constexpr int JB = 8, EL = 2;   // up to EL * JB row loads in flight per thread
+  const int L = a.L2, W = 1 << a.wsh, WN = W << ndsh;
+  const int totn = L << (a.wsh + ndsh);
+  const int N = a.L1 * a.L2;
+  const SrcMap& m = a.live.map;
+  const int nthr = blockDim.x;
+  for (int idx0 = threadIdx.x; idx0 < totn; idx0 += EL * nthr) {
+    int row[EL], nA[EL], jA[EL], jB[EL], T[EL], slot[EL];
+    const cplx* src[EL];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const int idx = idx0 + e * nthr;
+      const int i = idx >> (a.wsh + ndsh), cc = idx & (WN - 1);
+      const int day = cc >> a.wsh, c = cc & (W - 1), col = c0 + c;
+      row[e] = i;
+      slot[e] = (i << psh) + (day << a.wsh) + c;
+      nA[e] = 0; jA[e] = 0; jB[e] = 0; T[e] = 0;
+      src[e] = a.src;
+      if (idx < totn && col < a.ncols) {
+        int x0[2] = {0, 1}, x1[2] = {N - 1, 0};
+        if (a.live.on) {
+          int lo = -(1 << 30), hi = 1 << 30;
+          if (a.live.range) {
+            lo = a.live.range[2 * day];
+            hi = a.live.range[2 * day + 1];
+          }
+          x0[0] = max(0, lo - m.off1);
+          x1[0] = min(m.n1 - 1, hi - m.off1);
+          x0[1] = max(m.lo2, lo - m.off2 + m.lo2);
+          x1[1] = min(N - 1, hi - m.off2 + m.lo2);
+        }
+        int j0[2], cnt[2];
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+          j0[seg] = x0[seg] <= i ? 0 : ps_div(x0[seg] - i + L - 1, a.mgL2);
+          const int j1 = x1[seg] < i ? -1 : ps_div(x1[seg] - i, a.mgL2);
+          cnt[seg] = max(0, j1 - j0[seg] + 1);
+        }
+        jA[e] = j0[0]; nA[e] = cnt[0]; jB[e] = j0[1]; T[e] = cnt[0] + cnt[1];
+        src[e] = a.src + day * a.src_bstride + col;
+      }
+      if (idx >= totn) slot[e] = -1;
+    }
+    int tmax = 0;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) tmax = max(tmax, T[e]);
+    cplx acc[EL][G];
+#pragma unroll
+    for (int e = 0; e < EL; ++e)
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[e][g] = make_double2(0.0, 0.0);
+    for (int tb = 0; tb < tmax; tb += JB) {
+      cplx v[EL][JB];
+      int jj[EL][JB];
+#pragma unroll
+      for (int e = 0; e < EL; ++e)
+#pragma unroll
+        for (int t = 0; t < JB; ++t) {
+          const int tt = tb + t;
+          v[e][t] = make_double2(0.0, 0.0);
+          jj[e][t] = 0;
+          if (tt < T[e]) {
+            const int j = tt < nA[e] ? jA[e] + tt : jB[e] + tt - nA[e];
+            jj[e][t] = j;
+            v[e][t] = src[e][(int64_t)(row[e] + L * j) * a.ld];
+          }
+        }
+#pragma unroll
+      for (int e = 0; e < EL; ++e)
+#pragma unroll
+        for (int t = 0; t < JB; ++t)
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[e][g] = cadd(acc[e][g], cmul(v[e][t], wj[g * a.L1 + jj[e][t]]));
+    }
+#pragma unroll
+    for (int e = 0; e < EL; ++e)
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (slot[e] >= 0) data[slot[e] + (g << (a.wsh + ndsh))] = cmul(acc[e][g], stw[g * L + row[e]]);
+  }
+}
+
+// blockIdx -> (column tile, o).  Direct mode: the L1 workgroups that share one column tile
+// (= the same live-row slice of the kernel) are consecutive on ONE XCD (blocks go to the 8
+// XCDs round-robin), so the slice is fetched from HBM once and re-read out of that L2.
+__device__ __forceinline__ bool fused_tile_map(const ColFusedArgs& a, int ntiles, int* tile, int* o, int G = 1) {
+  const int nouter = a.L1 / G;   // workgroups per column tile
+  const int bx = blockIdx.x;
+  if (!a.direct) {
+    *tile = bx % ntiles;
+    *o = bx / ntiles;
+    return true;
+  }
+  const int xcd = bx & 7, q = bx >> 3;
+  const int grp = q / nouter;
+  *o = q - grp * nouter;
+  *tile = grp * 8 + xcd;
+  return *tile < ntiles;
+}
 
 template <bool GEN>
 __global__ void k_col_fused(ColFusedArgs a) {
@@ -390,8 +517,8 @@ __global__ void k_col_fused(ColFusedArgs a) {
   cplx* thi = tlo + P.n_lo;
   int* spos = reinterpret_cast<int*>(tlo + tw_count(P));
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
-  const int tile = blockIdx.x % ntiles;
-  const int o = blockIdx.x / ntiles;
+  int tile, o;
+  if (!fused_tile_map(a, ntiles, &tile, &o)) return;
   const int c0 = tile << a.wsh;
   const int nthr = blockDim.x;
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
@@ -399,6 +526,13 @@ __global__ void k_col_fused(ColFusedArgs a) {
   for (int r = threadIdx.x; r < L; r += nthr) spos[r] = (int)P.pos[r];
   const int tot = L << a.wsh;
   const int64_t base = (int64_t)o * a.L2;
+  if (a.direct) {
+    cplx* stw = reinterpret_cast<cplx*>(spos + ((L + 3) & ~3));
+    cplx* wj = stw + L;
+    kt_direct_tables(a, stw, wj, o);
+    __syncthreads();
+    kt_direct_fill<1>(a, data, stw, wj, c0, a.wsh, 0);
+  } else
   for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL];
 #pragma unroll
@@ -453,36 +587,48 @@ __global__ void k_col_fused(ColFusedArgs a) {
 // spectrum goes back to HBM, one inverse FFT, ND outputs.  HBM traffic per day drops from 4
 // spectra to (2 + 2 ND) / ND.  Valid while no day in the group raises the boundary flag: the
 // caller only groups days inside a speculation window (ps_chain_run).
-template <bool GEN, int ND>
+template <bool GEN, int ND, int G>
 __global__ void k_col_fused_multi(ColFusedArgs a) {
-  constexpr int NDSH = ND == 2 ? 1 : (ND == 4 ? 2 : 3);
-  static_assert(ND == 2 || ND == 4 || ND == 8, "ND must be 2, 4 or 8");
+  constexpr int NDSH = ND == 1 ? 0 : (ND == 2 ? 1 : (ND == 4 ? 2 : 3));
+  constexpr int GSH = G == 1 ? 0 : 1;
+  static_assert(ND == 1 || ND == 2 || ND == 4 || ND == 8, "ND must be 1, 2, 4 or 8");
+  static_assert(G == 1 || G == 2, "G must be 1 or 2");
   const FftProg& P = a.prog;
   const int L = P.L;
-  const int W = 1 << a.wsh, wshn = a.wsh + NDSH, WN = W << NDSH;
+  // tile columns: (g * ND + day) * W + c
+  const int W = 1 << a.wsh, wshd = a.wsh + NDSH, wshn = wshd + GSH, WN = W << (NDSH + GSH);
   cplx* data = reinterpret_cast<cplx*>(ps_lds_raw);
   cplx* tlo = data + ((size_t)L << wshn);
   cplx* thi = tlo + P.n_lo;
   int* spos = reinterpret_cast<int*>(thi + P.n_hi + P.n_gen);
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
-  const int tile = blockIdx.x % ntiles;
-  const int o = blockIdx.x / ntiles;
+  int tile, oq;
+  if (!fused_tile_map(a, ntiles, &tile, &oq, G)) return;
+  const int o0 = oq * G;
   const int c0 = tile << a.wsh;
   const int nthr = blockDim.x;
   load_tw(tlo, thi, P);
   for (int r = threadIdx.x; r < L; r += nthr) spos[r] = (int)P.pos[r];
-  const int tot = L << a.wsh, totn = L << wshn;
-  const int64_t base = (int64_t)o * a.L2;
+  const int totg = L << (a.wsh + GSH), totn = L << wshn;
+  if (a.direct) {
+    cplx* stw = reinterpret_cast<cplx*>(spos + ((L + 3) & ~3));
+    cplx* wj = stw + G * L;
+#pragma unroll
+    for (int g = 0; g < G; ++g) kt_direct_tables(a, stw + g * L, wj + g * a.L1, o0 + g);
+    __syncthreads();
+    kt_direct_fill<G>(a, data, stw, wj, c0, wshn, NDSH);
+  } else
   for (int idx0 = threadIdx.x; idx0 < totn; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL];
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
       const int idx = idx0 + u * nthr;
       const int row = idx >> wshn, cc = idx & (WN - 1);
-      const int day = cc >> a.wsh, col = c0 + (cc & (W - 1));
+      const int g = cc >> wshd, day = (cc >> a.wsh) & (ND - 1), col = c0 + (cc & (W - 1));
+      const int64_t grow = (int64_t)(o0 + g) * a.L2 + row;
       v[u] = make_double2(0.0, 0.0);
-      if (idx < totn && col < a.ncols && row_live(a.live, (int)(base + row), day))
-        v[u] = a.src[day * a.src_bstride + (base + row) * a.ld + col];
+      if (idx < totn && col < a.ncols && row_live(a.live, (int)grow, day))
+        v[u] = a.src[day * a.src_bstride + grow * a.ld + col];
     }
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
@@ -492,21 +638,22 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   }
   __syncthreads();
   lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, WN, wshn, 0);
-  for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
+  // elements (k, g, c): state row o0 + g + L1 k
+  for (int idx0 = threadIdx.x; idx0 < totg; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL];
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
       const int idx = idx0 + u * nthr;
-      const int k = idx >> a.wsh, col = c0 + (idx & (W - 1));
+      const int k = idx >> (a.wsh + GSH), g = (idx >> a.wsh) & (G - 1), col = c0 + (idx & (W - 1));
       v[u] = make_double2(0.0, 0.0);
-      if (idx < tot && col < a.ncols) v[u] = a.state[((int64_t)o + (int64_t)a.L1 * k) * a.ld + col];
+      if (idx < totg && col < a.ncols) v[u] = a.state[((int64_t)(o0 + g) + (int64_t)a.L1 * k) * a.ld + col];
     }
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
       const int idx = idx0 + u * nthr;
-      if (idx >= tot) continue;
-      const int k = idx >> a.wsh, c = idx & (W - 1);
-      const int l = (spos[k] << wshn) + c;
+      if (idx >= totg) continue;
+      const int k = idx >> (a.wsh + GSH), g = (idx >> a.wsh) & (G - 1), c = idx & (W - 1);
+      const int l = (spos[k] << wshn) + (g << wshd) + c;
       cplx x = v[u];
 #pragma unroll
       for (int day = 0; day < ND; ++day) {
@@ -514,15 +661,15 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
         data[l + (day << a.wsh)] = x;
       }
       if (a.store_prod && c0 + c < a.ncols)
-        a.state[((int64_t)o + (int64_t)a.L1 * k) * a.ld + c0 + c] = x;
+        a.state[((int64_t)(o0 + g) + (int64_t)a.L1 * k) * a.ld + c0 + c] = x;
     }
   }
   __syncthreads();
   lds_fft<PS_INV, GEN>(data, tlo, thi, P, PS_MODE_COL, WN, wshn, 0);
   for (int idx = threadIdx.x; idx < totn; idx += nthr) {
     const int row = idx >> wshn, cc = idx & (WN - 1);
-    const int day = cc >> a.wsh, col = c0 + (cc & (W - 1));
-    if (col < a.ncols) a.dst[day * a.dst_dstride + (base + row) * a.ld + col] = data[idx];
+    const int g = cc >> wshd, day = (cc >> a.wsh) & (ND - 1), col = c0 + (cc & (W - 1));
+    if (col < a.ncols) a.dst[day * a.dst_dstride + ((int64_t)(o0 + g) * a.L2 + row) * a.ld + col] = data[idx];
   }
 }
 
@@ -540,13 +687,18 @@ __global__ void k_col_fused_dual(ColFusedArgs a) {
   cplx* tlo = data + ((size_t)L << wsh2);
   cplx* thi = tlo + P.n_lo;
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
-  const int tile = blockIdx.x % ntiles;
-  const int o = blockIdx.x / ntiles;
+  int tile, o;
+  if (!fused_tile_map(a, ntiles, &tile, &o)) return;
   const int c0 = tile << a.wsh;
   const int nthr = blockDim.x;
   load_tw(tlo, thi, P);
   const int tot = L << a.wsh;
   const int64_t base = (int64_t)o * a.L2;
+  if (a.direct) {
+    cplx* stw = thi + P.n_hi + P.n_gen;
+    cplx* wj = stw + L;
+    kt_direct_tables(a, stw, wj, o);
+  }
   for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL], w[PS_UNROLL];
 #pragma unroll
@@ -556,7 +708,7 @@ __global__ void k_col_fused_dual(ColFusedArgs a) {
       v[u] = make_double2(0.0, 0.0);
       w[u] = v[u];
       if (idx < tot && col < a.ncols) {
-        if (row_live(a.live, (int)(base + row), 0)) v[u] = a.src[(base + row) * a.ld + col];
+        if (!a.direct && row_live(a.live, (int)(base + row), 0)) v[u] = a.src[(base + row) * a.ld + col];
         if (row_live(a.live2, (int)(base + row), 0)) w[u] = a.state[(base + row) * a.ld + col];
       }
     }
@@ -565,10 +717,15 @@ __global__ void k_col_fused_dual(ColFusedArgs a) {
       const int idx = idx0 + u * nthr;
       if (idx < tot) {
         const int row = idx >> a.wsh, c = idx & (W - 1);
-        data[(row << wsh2) + c] = v[u];
+        if (!a.direct) data[(row << wsh2) + c] = v[u];
         data[(row << wsh2) + W + c] = w[u];
       }
     }
+  }
+  if (a.direct) {
+    cplx* stw = thi + P.n_hi + P.n_gen;
+    __syncthreads();
+    kt_direct_fill<1>(a, data, stw, stw + L, c0, wsh2, 0);
   }
   __syncthreads();
   lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, 2 * W, wsh2, 0);

@@ -176,6 +176,7 @@ struct ps_solver {
   int nstat = 0;
   int last_renorm = 0;
   RowLive kt_live{0, {0, 0, 0, 0}, nullptr};  // live rows of the kernel transforms (non-split fused pass)
+  bool kt_direct = false;   // Bhat holds row-pass outputs: first column sub-pass by direct sum (kt_direct_fill)
   DevBuf<int> krange;                         // [nk][2] live source rows of each day kernel
   std::vector<int> hkrange;
   // staging for fetch / uploads
@@ -461,16 +462,26 @@ static int inv2d(ps_solver* s, const cplx* A, const cplx* B, cplx* prod, double*
 // forward transform of day kernels up to (not including) the last column sub-pass: that
 // one is fused with the spectral product and the first inverse sub-pass (k_col_fused)
 static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
-                         SrcMap rmap, SrcMap cmap, cplx* out, int batch, const int* rowrange = nullptr) {
+                         SrcMap rmap, SrcMap cmap, cplx* out, int batch, const int* rowrange = nullptr,
+                         bool direct = false) {
   const RowLive live{1, rmap, rowrange};
   s->kt_live = RowLive{0, {0, 0, 0, 0}, nullptr};
-  if (!s->split) {
+  s->kt_direct = s->split && direct;
+  if (!s->split || direct) {
     s->kt_live = live;  // the fused pass reads the row-pass output directly (one day at a time)
     return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr, 1, rowrange);
   }
   PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, nullptr, 1, rowrange));
   return launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, nullptr, live);
 }
+
+static void fused_direct_args(ps_solver* s, ColFusedArgs& a) {
+  a.direct = s->kt_direct ? 1 : 0;
+  a.tp_lo = s->tp_lo.p; a.tp_hi = s->tp_hi.p; a.tp_shift = s->tp_shift;
+  a.mgL2 = ps_magic((uint32_t)a.L2);
+}
+// LDS bytes of the direct-sum twiddles (stw[L2], wj[L1]) + alignment slack
+static size_t fused_direct_lds(const ColFusedArgs& a) { return a.direct ? ((size_t)a.L1 + a.L2 + 1) * sizeof(cplx) : 0; }
 
 static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst,
                             const int* rowrange) {
@@ -485,17 +496,22 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   a.live = s->kt_live;
   a.live.range = rowrange;
   a.prog = plan->prog;
+  a.dst_dstride = 0;
+  a.live2 = RowLive{0, {0, 0, 0, 0}, nullptr};
+  fused_direct_args(s, a);
   // 16-column tiles: the fused pass keeps four tile transfers in flight per workgroup, and
   // twice as many (smaller) workgroups per CU beat the 512-byte segments of W = 32 (+1.7 %)
   a.wsh = std::min(col_wsh(a.prog.L), 4);
   if (const char* e = getenv("PS_FUSED_WSH")) a.wsh = atoi(e);   // tuning knob
   auto need = [&](int wsh) {
-    return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+    return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
+           (size_t)(a.prog.L + 4) * sizeof(int) + fused_direct_lds(a);
   };
   while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 0) --a.wsh;
   if (need(a.wsh) > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "column pass needs %zu B LDS", need(a.wsh));
   const int W = 1 << a.wsh;
-  dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
+  const int ntiles = (s->H + W - 1) / W;
+  dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * a.L1), 1);   // see fused_tile_map
   ProfScope prof(s, PS_PROF_COL_INV_A);
   static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
   if (plan->generic)
@@ -524,26 +540,43 @@ static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* st
   a.live.range = rowrange;
   a.live2 = RowLive{0, {0, 0, 0, 0}, nullptr};
   a.prog = plan->prog;
-  const int ndsh = nd == 2 ? 1 : (nd == 4 ? 2 : 3);
+  fused_direct_args(s, a);
+  const int ndsh = nd == 1 ? 0 : nd == 2 ? 1 : (nd == 4 ? 2 : 3);
+  // direct mode: two outer indices per workgroup halve the re-reads of the live rows
+  static const int gopt = getenv("PS_FUSED_G") ? atoi(getenv("PS_FUSED_G")) : 2;   // tuning knob
+  const int G = (a.direct && gopt == 2 && a.L1 % 2 == 0) ? 2 : 1;
+  const int gsh = G == 2 ? 1 : 0;
   // 8-column tiles for four or more days: 37 KB of LDS per workgroup keeps four of them on a CU
   a.wsh = std::min(col_wsh(a.prog.L), nd >= 4 ? 3 : 4);
   if (const char* e = getenv("PS_MULTI_WSH")) a.wsh = atoi(e);   // tuning knob
   auto need = [&](int wsh) {
-    return (((size_t)a.prog.L << (wsh + ndsh)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + (size_t)a.prog.L * sizeof(int);
+    return (((size_t)a.prog.L << (wsh + ndsh + gsh)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
+           (size_t)(a.prog.L + 4) * sizeof(int) + G * fused_direct_lds(a);
   };
   while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
   *done = 0;
   if (need(a.wsh) > (size_t)kMaxLds) return PS_OK;
   const int W = 1 << a.wsh;
-  dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
-  ProfScope prof(s, nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4 : PS_PROF_COL_INV_A8);
-  static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
-#define PS_MULTI_LAUNCH(ND)                                                                                   \
-  if (plan->generic) hipLaunchKernelGGL((k_col_fused_multi<true, ND>), grid, dim3(fthr), need(a.wsh), s->stream, a); \
-  else hipLaunchKernelGGL((k_col_fused_multi<false, ND>), grid, dim3(fthr), need(a.wsh), s->stream, a)
-  if (nd == 2) { PS_MULTI_LAUNCH(2); }
-  else if (nd == 4) { PS_MULTI_LAUNCH(4); }
-  else { PS_MULTI_LAUNCH(8); }
+  const int ntiles = (s->H + W - 1) / W;
+  dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * (a.L1 / G)), 1);   // see fused_tile_map
+  ProfScope prof(s, nd == 1 ? PS_PROF_COL_INV_A : nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4 : PS_PROF_COL_INV_A8);
+  // the paired tile (74 KB at four days) leaves two workgroups per CU: 512 threads each keep 16 waves there
+  static const int fenv = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : 0;   // tuning knob
+  const int fthr = fenv ? fenv : (G == 2 ? 512 : col_threads());
+#define PS_MULTI_LAUNCH(ND, GG)                                                                                          \
+  if (plan->generic) hipLaunchKernelGGL((k_col_fused_multi<true, ND, GG>), grid, dim3(fthr), need(a.wsh), s->stream, a); \
+  else hipLaunchKernelGGL((k_col_fused_multi<false, ND, GG>), grid, dim3(fthr), need(a.wsh), s->stream, a)
+  if (G == 2) {
+    if (nd == 1) { PS_MULTI_LAUNCH(1, 2); }
+    else if (nd == 2) { PS_MULTI_LAUNCH(2, 2); }
+    else if (nd == 4) { PS_MULTI_LAUNCH(4, 2); }
+    else { PS_MULTI_LAUNCH(8, 2); }
+  } else {
+    if (nd == 1) { PS_MULTI_LAUNCH(1, 1); }
+    else if (nd == 2) { PS_MULTI_LAUNCH(2, 1); }
+    else if (nd == 4) { PS_MULTI_LAUNCH(4, 1); }
+    else { PS_MULTI_LAUNCH(8, 1); }
+  }
 #undef PS_MULTI_LAUNCH
   PS_HIP(hipGetLastError());
   *done = 1;
@@ -567,16 +600,19 @@ static int launch_col_fused_dual(ps_solver* s, const cplx* kt, const cplx* state
   a.live.range = rowrange;
   a.live2 = state_live;
   a.prog = plan->prog;
+  a.dst_dstride = 0;
+  fused_direct_args(s, a);
   a.wsh = std::min(col_wsh(a.prog.L), 4);
   if (const char* e = getenv("PS_DUAL_WSH")) a.wsh = atoi(e);   // tuning knob
   auto need = [&](int wsh) {
-    return (((size_t)a.prog.L << (wsh + 1)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
+    return (((size_t)a.prog.L << (wsh + 1)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + fused_direct_lds(a);
   };
   while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
   *done = 0;
   if (need(a.wsh) > (size_t)kMaxLds || getenv("PS_NO_DUAL")) return PS_OK;
   const int W = 1 << a.wsh;
-  dim3 grid((unsigned)(((s->H + W - 1) / W) * a.L1), 1);
+  const int ntiles = (s->H + W - 1) / W;
+  dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * a.L1), 1);   // see fused_tile_map
   ProfScope prof(s, PS_PROF_COL_INV_A);
   static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
   if (plan->generic)
@@ -935,8 +971,22 @@ static int transform_kernels(ps_solver* s, int first, int count) {
                        s->kval.p, s->dkoff.p, s->dkshape.p, first, s->kdense.p, K);
     PS_HIP(hipGetLastError());
   }
+  // compact kernels (few live rows per residue class of the column split): skip the first
+  // column sub-pass, the fused pass sums the live rows directly (kt_direct_fill)
+  bool direct = s->split && getenv("PS_NO_DIRECT") == nullptr;
+  if (direct) {
+    static const int max_terms = getenv("PS_DIRECT_MAX_TERMS") ? atoi(getenv("PS_DIRECT_MAX_TERMS")) : 8;   // tuning knob
+    for (int d = first; d < first + count && direct; ++d) {
+      const int lo = s->hkrange[2 * d], hi = s->hkrange[2 * d + 1];
+      if (lo > hi) continue;
+      // live rows split at the kernel centre M into the two wrapped intervals
+      const int below = std::max(0, std::min(hi, M - 1) - lo + 1), above = std::max(0, hi - std::max(lo, M) + 1);
+      const int terms = (below + s->L2 - 1) / s->L2 + (above + s->L2 - 1) / s->L2;
+      if (terms > max_terms) direct = false;
+    }
+  }
   PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count,
-                       s->krange.p + 2 * first));
+                       s->krange.p + 2 * first, direct));
   s->bhat_first = first;
   s->bhat_count = count;
   return PS_OK;
@@ -1143,8 +1193,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
         // inside a window no flag is expected: days go through the fused pass in groups
         for (int i = 0; i < w;) {
           int g = 0;
-          if (s->fused_days > 1 && w - i >= 2) {
-            const int nd = (s->fused_days >= 8 && w - i >= 8) ? 8 : (s->fused_days >= 4 && w - i >= 4) ? 4 : 2;
+          // direct mode pairs outer indices (twice the tile): four days per pass there
+          static const int direct_days = getenv("PS_DIRECT_DAYS") ? atoi(getenv("PS_DIRECT_DAYS")) : 4;   // tuning knob
+          const int maxd = s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days;
+          if (maxd > 1 && w - i >= 2) {
+            const int nd = (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
             const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
             PS_TRY(conv_inv_multi(s, B, nd, s->Ahat.p, &s->recs[PS_REC_CHAIN][d + i], d + i, negval, stat_scale,
                                   s->krange.p + 2 * (d + i), &g));
