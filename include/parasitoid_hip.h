@@ -80,6 +80,9 @@ int ps_solver_destroy(ps_solver* s);
 /* P = reference torus, Pfft = transform size in use, H = Pfft/2+1 */
 int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H);
 int ps_solver_sync(ps_solver* s);
+/* measurement aid: 1 when the day kernels of the last transformed chunk were compact enough
+ * for the direct-sum first column sub-pass inside the fused kernel (no separate launch) */
+int ps_solver_kernels_direct(ps_solver* s);
 
 /* CudaSolve.__init__ (cuda_lib.py:34-54) / CalcSol.fft2 (CalcSol.py:11-24):
  * state_hat = FFT2(zero-padded N x N sparse field). */

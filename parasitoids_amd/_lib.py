@@ -70,6 +70,7 @@ SIGNATURES = {
                                   C.POINTER(DayStats)]),
     'ps_solver_retarget': (C.c_int, [_VP, C.c_int]),
     'ps_fast_size': (C.c_int, [C.c_int, C.c_int]),
+    'ps_solver_kernels_direct': (C.c_int, [_VP]),
     'ps_record_fetch_coo': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                       C.c_double, _I32P, _I32P, _F64P, C.c_int64, _I64P]),
     'ps_record_fetch_csr': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,

@@ -1550,6 +1550,8 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
   return PS_OK;
 }
 
+extern "C" int ps_solver_kernels_direct(ps_solver* s) { return s && s->kt_direct ? 1 : 0; }
+
 int ps_solver_dom_len_internal(ps_solver* s) { return s->N; }
 int ps_solver_device_internal(ps_solver* s) { return s->device; }
 

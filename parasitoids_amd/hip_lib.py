@@ -262,6 +262,12 @@ class HipSolve():
     def sync(self):
         L.check(self._lib.ps_solver_sync(self._h))
 
+    @property
+    def kernels_direct(self):
+        '''True when the last chunk of day kernels took the direct-sum first column sub-pass
+        (compact kernels on a split column transform) -- measurement aid.'''
+        return bool(self._lib.ps_solver_kernels_direct(self._h))
+
     PROF_CLASSES = ('row_fwd', 'col_fwd_a', 'col_fwd_b', 'col_inv_a', 'col_inv_b', 'row_inv',
                     'refft_pred', 'col_inv_a_x2', 'col_inv_a_x4', 'col_inv_a_x8')
 

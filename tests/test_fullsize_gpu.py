@@ -260,3 +260,66 @@ def test_every_register_resident_size(hip_lib, monkeypatch):
         done += 1
     monkeypatch.delenv('PS_NO_RS', raising=False)
     assert done >= 35
+
+
+def test_direct_sum_subpass_matches_fft_subpass(hip_lib, monkeypatch):
+    """Compact day kernels on a split column transform take the direct-sum first column
+    sub-pass inside the fused kernel (kt_direct_fill); PS_NO_DIRECT=1 forces the FFT sub-pass.
+    Same chains, both ways: supports on one side of the kernel centre only, a single row,
+    spans at and beyond the term limit (fallback), an empty day kernel, mixed shapes; fast
+    mode (multi-day fused passes, flags off) and fold mode (dual-forward fused pass)."""
+    R, K = 640, 801
+    N, M = 2 * R + 1, K // 2
+    rng = np.random.default_rng(77)
+    st = sparse.coo_matrix((rng.random(300) + 0.1,
+                            (rng.integers(R - 60, R + 60, 300), rng.integers(R - 60, R + 60, 300))), shape=(N, N))
+    st = (st / st.sum()).tocoo()
+
+    def kern(rows_lo, rows_hi, shape=K, n=400, seed=0):
+        r = np.random.default_rng(seed)
+        m = shape // 2
+        if rows_hi < rows_lo:
+            return sparse.coo_matrix((shape, shape))
+        k = sparse.coo_matrix((r.random(n) + 0.05,
+                               (r.integers(rows_lo, rows_hi + 1, n), r.integers(m - 40, m + 41, n))),
+                              shape=(shape, shape))
+        k.sum_duplicates()
+        return (k / k.sum()).tocoo()
+
+    spans = [(M - 20, M + 20), (M + 3, M + 30), (M - 35, M - 2), (M, M), (0, K - 1), (1, 0),
+             (M - 70, M + 69), (M - 5, M + 5), (M - 12, M + 9), (M - 1, M + 40), (M - 40, M + 1)]
+    kernels = [kern(lo, hi, seed=i) for i, (lo, hi) in enumerate(spans)]
+    kernels.append(kern(40, 60, shape=101, seed=99))   # smaller shape inside the staging box
+    kernels.append(kern(M - 8, M + 8, seed=100))
+    kernels.append(kern(M - 3, M + 25, seed=101))
+    nd = len(kernels)
+    compact = [k for i, k in enumerate(kernels) if spans[min(i, len(spans) - 1)] != (0, K - 1)]
+    assert len(compact) % 2 == 1    # windows 2, 4, 6 -> one single-day fused pass at the end
+    # a second state next to the domain edge: boundary flags fire, speculation ends, the
+    # single-day fused pass and the flag-conditional re-FFT run with direct-sum kernels
+    edge = sparse.coo_matrix((rng.random(50) + 0.1, (rng.integers(2, 30, 50), rng.integers(R - 20, R + 20, 50))),
+                             shape=(N, N))
+    edge = (edge / edge.sum()).tocoo()
+    flagged = False
+    for mode, ks, st in (('fast', kernels, st), ('fast', compact, st), ('fold', compact, st), ('fold', kernels, st),
+                         ('fast', compact, edge), ('fold', compact, edge)):
+        out = {}
+        for tag in ('direct', 'fft'):
+            if tag == 'fft':
+                monkeypatch.setenv('PS_NO_DIRECT', '1')
+            else:
+                monkeypatch.delenv('PS_NO_DIRECT', raising=False)
+            s = hip_lib.HipSolve(st, [K, K], mode=mode, chain_only=(mode == 'fold'))
+            assert s.fft_len > 1200      # split column transform
+            s.set_kernels(ks)
+            s.run_chain(renorm=False)
+            stats = s.chain_stats(0, len(ks))
+            out[tag] = ([s.dense(0, d) for d in range(len(ks))], [x.flag for x in stats], s.kernels_direct)
+            s.close()
+        assert out['fft'][2] is False
+        assert out['direct'][2] is (ks is compact)   # the full-height kernel falls back
+        assert out['direct'][1] == out['fft'][1]
+        flagged = flagged or (st is edge and any(out['direct'][1]))
+        for a, b in zip(out['direct'][0], out['fft'][0]):
+            assert np.abs(a - b).max() <= 1e-15 * max(1.0, np.abs(b).max()) + 2e-17
+    assert flagged
