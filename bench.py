@@ -42,8 +42,8 @@ ALG_P2 = {
 DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8}
 # kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
 PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1',
-            'col_inv_a_x2': 'void k_col_fused_multi<false, 2>', 'col_inv_a_x4': 'void k_col_fused_multi<false, 4>',
-            'col_inv_a_x8': 'void k_col_fused_multi<false, 8>'}
+            'col_inv_a_x2': 'void k_col_fused_multi<false, 2,', 'col_inv_a_x4': 'void k_col_fused_multi<false, 4,',
+            'col_inv_a_x8': 'void k_col_fused_multi<false, 8,'}
 
 
 def pmc_traffic(kernel_class):

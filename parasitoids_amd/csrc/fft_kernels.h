@@ -694,11 +694,6 @@ __global__ void k_col_fused_dual(ColFusedArgs a) {
   load_tw(tlo, thi, P);
   const int tot = L << a.wsh;
   const int64_t base = (int64_t)o * a.L2;
-  if (a.direct) {
-    cplx* stw = thi + P.n_hi + P.n_gen;
-    cplx* wj = stw + L;
-    kt_direct_tables(a, stw, wj, o);
-  }
   for (int idx0 = threadIdx.x; idx0 < tot; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL], w[PS_UNROLL];
 #pragma unroll
@@ -708,7 +703,7 @@ __global__ void k_col_fused_dual(ColFusedArgs a) {
       v[u] = make_double2(0.0, 0.0);
       w[u] = v[u];
       if (idx < tot && col < a.ncols) {
-        if (!a.direct && row_live(a.live, (int)(base + row), 0)) v[u] = a.src[(base + row) * a.ld + col];
+        if (row_live(a.live, (int)(base + row), 0)) v[u] = a.src[(base + row) * a.ld + col];
         if (row_live(a.live2, (int)(base + row), 0)) w[u] = a.state[(base + row) * a.ld + col];
       }
     }
@@ -717,15 +712,10 @@ __global__ void k_col_fused_dual(ColFusedArgs a) {
       const int idx = idx0 + u * nthr;
       if (idx < tot) {
         const int row = idx >> a.wsh, c = idx & (W - 1);
-        if (!a.direct) data[(row << wsh2) + c] = v[u];
+        data[(row << wsh2) + c] = v[u];
         data[(row << wsh2) + W + c] = w[u];
       }
     }
-  }
-  if (a.direct) {
-    cplx* stw = thi + P.n_hi + P.n_gen;
-    __syncthreads();
-    kt_direct_fill<1>(a, data, stw, stw + L, c0, wsh2, 0);
   }
   __syncthreads();
   lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, 2 * W, wsh2, 0);

@@ -601,11 +601,11 @@ static int launch_col_fused_dual(ps_solver* s, const cplx* kt, const cplx* state
   a.live2 = state_live;
   a.prog = plan->prog;
   a.dst_dstride = 0;
-  fused_direct_args(s, a);
+  fused_direct_args(s, a);   // never direct in PS_MODE_FOLD (transform_kernels)
   a.wsh = std::min(col_wsh(a.prog.L), 4);
   if (const char* e = getenv("PS_DUAL_WSH")) a.wsh = atoi(e);   // tuning knob
   auto need = [&](int wsh) {
-    return (((size_t)a.prog.L << (wsh + 1)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) + fused_direct_lds(a);
+    return (((size_t)a.prog.L << (wsh + 1)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   };
   while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
   *done = 0;
@@ -973,7 +973,10 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   }
   // compact kernels (few live rows per residue class of the column split): skip the first
   // column sub-pass, the fused pass sums the live rows directly (kt_direct_fill)
-  bool direct = s->split && getenv("PS_NO_DIRECT") == nullptr;
+  // (measured: +14 % on the headline stack, whose kernels need 6-8 terms per output; break-even
+  // near 8 terms at FFT size 5760; the fold-mode fused pass, with the state in the other half of
+  // its tile, does not gain)
+  bool direct = s->split && s->mode != PS_MODE_FOLD && getenv("PS_NO_DIRECT") == nullptr;
   if (direct) {
     static const int max_terms = getenv("PS_DIRECT_MAX_TERMS") ? atoi(getenv("PS_DIRECT_MAX_TERMS")) : 8;   // tuning knob
     for (int d = first; d < first + count && direct; ++d) {

@@ -267,7 +267,8 @@ def test_direct_sum_subpass_matches_fft_subpass(hip_lib, monkeypatch):
     sub-pass inside the fused kernel (kt_direct_fill); PS_NO_DIRECT=1 forces the FFT sub-pass.
     Same chains, both ways: supports on one side of the kernel centre only, a single row,
     spans at and beyond the term limit (fallback), an empty day kernel, mixed shapes; fast
-    mode (multi-day fused passes, flags off) and fold mode (dual-forward fused pass)."""
+    mode (multi-day fused passes; single-day pass and re-FFT once flags fire); fold mode runs
+    the same chains for reference (it never takes the direct route)."""
     R, K = 640, 801
     N, M = 2 * R + 1, K // 2
     rng = np.random.default_rng(77)
@@ -317,7 +318,8 @@ def test_direct_sum_subpass_matches_fft_subpass(hip_lib, monkeypatch):
             out[tag] = ([s.dense(0, d) for d in range(len(ks))], [x.flag for x in stats], s.kernels_direct)
             s.close()
         assert out['fft'][2] is False
-        assert out['direct'][2] is (ks is compact)   # the full-height kernel falls back
+        # the full-height kernel falls back; fold mode always takes the FFT sub-pass
+        assert out['direct'][2] is (ks is compact and mode == 'fast')
         assert out['direct'][1] == out['fft'][1]
         flagged = flagged or (st is edge and any(out['direct'][1]))
         for a, b in zip(out['direct'][0], out['fft'][0]):
