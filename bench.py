@@ -234,8 +234,13 @@ def main():
                        'dom_len': N, 'ndays': nd, 'kshape': K, 'P': P, 'fft_len': solver.fft_len},
             'alg_bytes_per_grid_day': 96.0 * P * P,
             'alg_GBps_whole_chain': round(value / world * 96.0 * P * P / 1e9, 1),
+            # achieved/frac: ALGORITHMIC bytes of the unfused pipeline model per launch
+            # / launch time -- above 1 when the launch keeps intermediates in LDS; traffic and
+            # traffic_GBps: bytes the launch really moved (rocprofv3 PMC) and their rate
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'traffic_GBps': (round(traffic / (kern[dom]['avg_ms'] * 1e-3) / 1e9, 1)
+                                          if traffic else None),
                          'alg_bytes_per_launch': alg_p2[dom] * P * P, 'traffic_source': traffic_src},
             'kernels': kern,
         }

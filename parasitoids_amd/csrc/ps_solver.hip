@@ -560,9 +560,9 @@ static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* st
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * (a.L1 / G)), 1);   // see fused_tile_map
   ProfScope prof(s, nd == 1 ? PS_PROF_COL_INV_A : nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4 : PS_PROF_COL_INV_A8);
-  // the paired tile (74 KB at four days) leaves two workgroups per CU: 512 threads each keep 16 waves there
+  // the paired tile (74 KB at two or four days) leaves two workgroups per CU: 512 threads each keep 16 waves there
   static const int fenv = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : 0;   // tuning knob
-  const int fthr = fenv ? fenv : (G == 2 ? 512 : col_threads());
+  const int fthr = fenv ? fenv : (G == 2 && nd > 1 ? 512 : col_threads());
 #define PS_MULTI_LAUNCH(ND, GG)                                                                                          \
   if (plan->generic) hipLaunchKernelGGL((k_col_fused_multi<true, ND, GG>), grid, dim3(fthr), need(a.wsh), s->stream, a); \
   else hipLaunchKernelGGL((k_col_fused_multi<false, ND, GG>), grid, dim3(fthr), need(a.wsh), s->stream, a)
@@ -627,7 +627,10 @@ static int launch_col_fused_dual(ps_solver* s, const cplx* kt, const cplx* state
 // one day step: state_hat <- state_hat * K_hat (stored when store_prod), rec <- ifft2(...)
 static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, double* rec,
                     int stat_slot, double negval, double stat_scale, const int* rowrange = nullptr) {
-  PS_TRY(launch_col_fused(s, kt, state, store_prod, s->T1.p, rowrange));
+  int done = 0;
+  // direct-sum kernels: the one-day instance of the multi kernel pairs outer indices (+5 %)
+  if (s->kt_direct && store_prod) PS_TRY(launch_col_fused_multi(s, kt, 1, state, s->T1.p, rowrange, &done));
+  if (!done) PS_TRY(launch_col_fused(s, kt, state, store_prod, s->T1.p, rowrange));
   if (!s->split) return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
   PS_TRY(launch_col<PS_INV>(s, s->inv_passes[1], s->T1.p, nullptr, nullptr, s->T2.p, 1, 0, nullptr));
   return launch_row_inv(s, s->T2.p, rec, stat_slot, 1, negval, stat_scale);
