@@ -283,7 +283,13 @@ static int set_lds_attr() {
                       (const void*)k_row_inv<false, true>,
                       (const void*)k_col<PS_FWD, false>, (const void*)k_col<PS_FWD, true>,
                       (const void*)k_col<PS_INV, false>, (const void*)k_col<PS_INV, true>,
-                      (const void*)k_col_fused<false>, (const void*)k_col_fused<true>};
+                      (const void*)k_col_fused<false>, (const void*)k_col_fused<true>,
+                      (const void*)k_col_fused_dual<false>, (const void*)k_col_fused_dual<true>,
+#define PS_MULTI_K(ND) \
+  (const void*)k_col_fused_multi<false, ND, 1>, (const void*)k_col_fused_multi<true, ND, 1>, \
+  (const void*)k_col_fused_multi<false, ND, 2>, (const void*)k_col_fused_multi<true, ND, 2>
+                      PS_MULTI_K(1), PS_MULTI_K(2), PS_MULTI_K(4), PS_MULTI_K(8)};
+#undef PS_MULTI_K
   for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
 #define X(A, B)                                                                                              \
   {                                                                                                          \
@@ -553,9 +559,11 @@ static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* st
     return (((size_t)a.prog.L << (wsh + ndsh + gsh)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
            (size_t)(a.prog.L + 4) * sizeof(int) + G * fused_direct_lds(a);
   };
-  while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
+  // at least two workgroups per CU, or the single-day pass does better
+  const size_t lds_cap = (size_t)kMaxLds / 2;
+  while (need(a.wsh) > lds_cap && a.wsh > 2) --a.wsh;
   *done = 0;
-  if (need(a.wsh) > (size_t)kMaxLds) return PS_OK;
+  if (need(a.wsh) > lds_cap) return PS_OK;
   const int W = 1 << a.wsh;
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * (a.L1 / G)), 1);   // see fused_tile_map
