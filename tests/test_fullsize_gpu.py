@@ -325,3 +325,28 @@ def test_direct_sum_subpass_matches_fft_subpass(hip_lib, monkeypatch):
         for a, b in zip(out['direct'][0], out['fft'][0]):
             assert np.abs(a - b).max() <= 1e-15 * max(1.0, np.abs(b).max()) + 2e-17
     assert flagged
+
+
+@pytest.mark.parametrize('R,K,mode', [(640, 801, 'fast'), (600, 221, 'exact'), (400, 201, 'exact'), (700, 301, 'fast')])
+def test_multi_day_fused_pass_is_bit_identical(hip_lib, monkeypatch, R, K, mode):
+    """Un-flagged days go through the fused column pass in groups of up to 8
+    (k_col_fused_multi): the same products in the same order as single-day passes, so every
+    record must be BIT-identical to PS_FUSED_DAYS=1 -- split and single-pass column
+    transforms, smooth and generic (prime factor 19, 23, 17, 53) plans, 11 days (groups of
+    2, 4, 4 + 1).  The direct-sum route is switched off here: it changes round-off."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_NO_DIRECT', '1')
+    nd = 11
+    state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=3, sigma=(2.0, 6.0), shift=4.0)
+    out = {}
+    for days in ('1', '8'):
+        monkeypatch.setenv('PS_FUSED_DAYS', days)
+        s = hip_lib.HipSolve(state, [K, K], mode=mode)
+        s.set_kernels(kernels)
+        s.run_chain(renorm=False)
+        st = s.chain_stats(0, nd)
+        assert not any(x.flag for x in st)
+        out[days] = [s.dense(0, d) for d in range(nd)]
+        s.close()
+    for a, b in zip(out['1'], out['8']):
+        assert np.array_equal(a, b)
