@@ -77,7 +77,7 @@ def parse():
     ap.add_argument('--ndays', type=int, default=30)
     ap.add_argument('--mode', default='fast', choices=['fast', 'exact', 'fold', 'auto'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-days', type=int, default=2)
+    ap.add_argument('--cpu-days', type=int, default=6)   # ~10 s of one host core
     return ap.parse_args()
 
 
