@@ -489,6 +489,44 @@ __device__ __forceinline__ void kt_direct_fill(const ColFusedArgs& a, cplx* data
   }
 }
 
+// Workgroup prologue of the fused kernels: FFT twiddle block, digit-reversal table and (direct
+// mode) the stw / wj tables of G outer indices, with ALL global loads of a round issued before
+// the first LDS store -- one memory round trip instead of one per table (they used to be six
+// of a workgroup's ~25 us).
+template <int G>
+__device__ __forceinline__ void fused_prologue(const ColFusedArgs& a, cplx* tlo, int* spos, cplx* stw, cplx* wj,
+                                               int o0) {
+  const FftProg& P = a.prog;
+  const int n = tw_count(P), L = P.L;
+  const int n_stw = a.direct ? G * a.L2 : 0, n_dir = a.direct ? G * (a.L2 + a.L1) : 0;
+  const int nmax = max(max(n, L), n_dir);
+  const int mask = (1 << a.tp_shift) - 1;
+  for (int t = threadIdx.x; t < nmax; t += blockDim.x) {
+    cplx tv = make_double2(0.0, 0.0), hi = tv, lo = tv;
+    int sp = 0, dst = 0;
+    if (t < n) tv = P.tw_lo[t];
+    if (t < L) sp = (int)P.pos[t];
+    if (t < n_dir) {
+      int e;
+      if (t < n_stw) {                       // stw[g * L2 + r] = w_N^{(o0 + g) r}
+        const int g = t / a.L2, r = t - g * a.L2;
+        e = (o0 + g) * r;
+        dst = t;
+      } else {                               // wj[g * L1 + j] = w_L1^{j (o0 + g)}
+        const int u = t - n_stw;
+        const int g = u / a.L1, j = u - g * a.L1;
+        e = ((j * (o0 + g)) % a.L1) * a.L2;
+        dst = u;
+      }
+      hi = a.tp_hi[e >> a.tp_shift];
+      lo = a.tp_lo[e & mask];
+    }
+    if (t < n) tlo[t] = tv;
+    if (t < L) spos[t] = sp;
+    if (t < n_dir) (t < n_stw ? stw : wj)[dst] = cmul(hi, lo);
+  }
+}
+
 // blockIdx -> (column tile, o).  Direct mode: the L1 workgroups that share one column tile
 // (= the same live-row slice of the kernel) are consecutive on ONE XCD (blocks go to the 8
 // XCDs round-robin), so the slice is fetched from HBM once and re-read out of that L2.
@@ -607,14 +645,11 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   const int o0 = oq * G;
   const int c0 = tile << a.wsh;
   const int nthr = blockDim.x;
-  load_tw(tlo, thi, P);
-  for (int r = threadIdx.x; r < L; r += nthr) spos[r] = (int)P.pos[r];
+  cplx* stw = reinterpret_cast<cplx*>(spos + ((L + 3) & ~3));
+  cplx* wj = stw + G * L;
+  fused_prologue<G>(a, tlo, spos, stw, wj, o0);
   const int totg = L << (a.wsh + GSH), totn = L << wshn;
   if (a.direct) {
-    cplx* stw = reinterpret_cast<cplx*>(spos + ((L + 3) & ~3));
-    cplx* wj = stw + G * L;
-#pragma unroll
-    for (int g = 0; g < G; ++g) kt_direct_tables(a, stw + g * L, wj + g * a.L1, o0 + g);
     __syncthreads();
     kt_direct_fill<G>(a, data, stw, wj, c0, wshn, NDSH);
   } else
