@@ -406,7 +406,7 @@ __device__ __forceinline__ void kt_direct_tables(const ColFusedArgs& a, cplx* st
 // of the tile, tables stw[g * L2 + i], wj[g * L1 + j]
 template <int G>
 __device__ __forceinline__ void kt_direct_fill(const ColFusedArgs& a, cplx* data, const cplx* stw, const cplx* wj,
-                                               int c0, int psh, int ndsh) {
+                                               int c0, int psh, int ndsh, const int* rng = nullptr) {
   constexpr int JB = 8, EL = 2;   // up to EL * JB row loads in flight per thread
   const int L = a.L2, W = 1 << a.wsh, WN = W << ndsh;
   const int totn = L << (a.wsh + ndsh);
@@ -429,7 +429,10 @@ __device__ __forceinline__ void kt_direct_fill(const ColFusedArgs& a, cplx* data
         int x0[2] = {0, 1}, x1[2] = {N - 1, 0};
         if (a.live.on) {
           int lo = -(1 << 30), hi = 1 << 30;
-          if (a.live.range) {
+          if (rng) {   // LDS copy (fused_prologue): no global round trip ahead of the row loads
+            lo = rng[2 * day];
+            hi = rng[2 * day + 1];
+          } else if (a.live.range) {
             lo = a.live.range[2 * day];
             hi = a.live.range[2 * day + 1];
           }
@@ -495,9 +498,12 @@ __device__ __forceinline__ void kt_direct_fill(const ColFusedArgs& a, cplx* data
 // of a workgroup's ~25 us).
 template <int G>
 __device__ __forceinline__ void fused_prologue(const ColFusedArgs& a, cplx* tlo, int* spos, cplx* stw, cplx* wj,
-                                               int o0) {
+                                               int o0, int* rng, int nd) {
   const FftProg& P = a.prog;
   const int n = tw_count(P), L = P.L;
+  // per-day live row ranges of the kernels (direct mode) -> LDS
+  if (a.direct && (int)threadIdx.x < 2 * nd)
+    rng[threadIdx.x] = a.live.range ? a.live.range[threadIdx.x] : ((threadIdx.x & 1) ? (1 << 30) : -(1 << 30));
   const int n_stw = a.direct ? G * a.L2 : 0, n_dir = a.direct ? G * (a.L2 + a.L1) : 0;
   const int nmax = max(max(n, L), n_dir);
   const int mask = (1 << a.tp_shift) - 1;
@@ -647,11 +653,12 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   const int nthr = blockDim.x;
   cplx* stw = reinterpret_cast<cplx*>(spos + ((L + 3) & ~3));
   cplx* wj = stw + G * L;
-  fused_prologue<G>(a, tlo, spos, stw, wj, o0);
+  int* rng = reinterpret_cast<int*>(wj + G * a.L1);   // [ND][2]
+  fused_prologue<G>(a, tlo, spos, stw, wj, o0, rng, ND);
   const int totg = L << (a.wsh + GSH), totn = L << wshn;
   if (a.direct) {
     __syncthreads();
-    kt_direct_fill<G>(a, data, stw, wj, c0, wshn, NDSH);
+    kt_direct_fill<G>(a, data, stw, wj, c0, wshn, NDSH, rng);
   } else
   for (int idx0 = threadIdx.x; idx0 < totn; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL];

@@ -487,7 +487,7 @@ static void fused_direct_args(ps_solver* s, ColFusedArgs& a) {
   a.mgL2 = ps_magic((uint32_t)a.L2);
 }
 // LDS bytes of the direct-sum twiddles (stw[L2], wj[L1]) + alignment slack
-static size_t fused_direct_lds(const ColFusedArgs& a) { return a.direct ? ((size_t)a.L1 + a.L2 + 1) * sizeof(cplx) : 0; }
+static size_t fused_direct_lds(const ColFusedArgs& a) { return a.direct ? ((size_t)a.L1 + a.L2 + 1) * sizeof(cplx) + 64 : 0; }   // + day ranges
 
 static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst,
                             const int* rowrange) {
