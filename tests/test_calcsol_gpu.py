@@ -177,3 +177,29 @@ def test_fetch_csr_equals_coo_tocsr(golden):
     e = s._fetch(L.REC_CHAIN, 0, 10.0, 1.0, 0.0, 1.0, 0, 'csr')
     assert e.nnz == 0 and e.shape == (257, 257) and not e.indptr.any()
     s.close()
+
+
+def test_baseline_config2_population_model_1024(golden_dir):
+    """BASELINE.json configs[1]: Run.py --pop, 1024 x 1024 grid (R = 512, N = 1025), 30 days,
+    fp64 -- the device chain (default 'auto' mode: the reference's own torus) against the
+    oracle's get_populations on the SAME day kernels (device prob_mass, whose parity has its own
+    tests).  Values reach r_number = 40 000, so 1e-7 absolute is 2.5e-12 relative."""
+    from oracle import calcsol as OC
+    from parasitoids_amd import ParasitoidModel as PM
+    Run, p = _params(golden_dir, '--carnarvon', '--pop', 'r_dur=1', 'domain_info=(40000.0,512)')
+    modelsol, days, ndays, _ = Run.run_model(p, verbose=False)
+    assert ndays == 30 and modelsol[0].shape == (1025, 1025)
+    wind_data, days2 = PM.get_wind_data(*p.get_wind_params())
+    starts = [p.r_start] + [None] * (ndays - 1)
+    pmf_list = PM.prob_mass_batch(days2[:ndays], wind_data, *p.get_model_params(), start_times=starts)
+    max_shape = np.array([0, 0])
+    for pmf in pmf_list:
+        max_shape = np.maximum(max_shape, pmf.shape)
+    r_spread = [recentre(pmf_list[0], 512).tocsr()]
+    ref = OC.get_populations(r_spread, pmf_list, days2, ndays, 1025, max_shape, 1, p.r_number,
+                             p.r_mthd())
+    assert len(ref) == len(modelsol) == 30
+    for i, (a, b) in enumerate(zip(modelsol, ref)):
+        d = abs(a.tocsr() - b.tocsr())
+        assert (d.max() if d.nnz else 0.0) < 1e-7, i
+        assert abs(a.sum() - b.sum()) < 1e-6 * max(1.0, abs(b.sum()))
