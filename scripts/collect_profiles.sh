@@ -16,7 +16,7 @@ python3 "$root/scripts/run_mcmc.py" --samples 200 --mode fast >> "$out/${tag}_mc
 for m in auto exact; do python3 "$root/bench.py" --mode $m --steps 3 --warmup 1 --no-cpu-baseline >> "$out/${tag}_bench_modes.json" 2>> "$out/${tag}_bench.err"; done
 for cfg in "1024 1025" "512 513" "1024 1641" "2048 3201"; do set -- $cfg; python3 "$root/bench.py" --rad-res $1 --kshape $2 --no-cpu-baseline >> "$out/${tag}_bench_other_sizes.json" 2>> "$out/${tag}_bench.err"; done
 python3 "$root/scripts/hbm_calib.py" > "$out/${tag}_hbm_calibration.txt" 2>&1
-python3 "$root/scripts/parity_report.py" > "$out/${tag}_parity_report.txt" 2>&1 || true
+python3 "$root/tests/parity_report.py" > "$out/${tag}_parity_report.txt" 2>&1 || true
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$out/${tag}_kt" -o kt --output-format csv -- \
   python3 "$root/bench.py" --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2>> "$out/${tag}_bench.err"

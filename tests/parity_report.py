@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measured deviations of the device path from the reference's golden vectors and from the
 oracle (what the -m gpu tests assert, as numbers).  Run on the GPU box:
-    python scripts/parity_report.py > profiles/rNN_parity_report.txt
+    python tests/parity_report.py > profiles/rNN_parity_report.txt
 """
 import os
 import sys
