@@ -182,3 +182,32 @@ def test_locinfo_loader_kalbar():
     assert [a.shape[0] for a in li.card_obs] == [4, 4] and [t.days for t in li.card_obs_datesPR] == [2, 8]
     for a, name in zip(li.card_obs, ('kalbar_cardinal_15mar05.csv', 'kalbar_cardinal_21mar05.csv')):
         assert a.sum() == sum(int(r['num adults']) for r in rows(name))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The newest committed `bench.py` line (profiles/rNN_vMM_bench.json, produced on the GPU
+    box) carries every field the bench contract names, with consistent values."""
+    import glob
+    import json
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench.json')),
+                   key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+              'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'grid-days/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['vs_baseline'] is None and d['dtype'] == 'f64' and d['n_gpus'] == 1
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1
+    # value and ms_per_step describe the same run: 30-day stacks
+    assert abs(d['value'] - d['n_gpus'] * d['config']['ndays'] / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
