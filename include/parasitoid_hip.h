@@ -152,6 +152,12 @@ int ps_record_fetch_dense(ps_solver* s, int kind, int idx, double* out /* N*N */
  * popdensity_to_emergence (Bayes_funcs.py:20-179), without shipping the field to the host. */
 int ps_record_gather(ps_solver* s, int kind, int idx, int64_t n, const int32_t* rows,
                      const int32_t* cols, double scale, double negval, double* out);
+/* The same cells from nrec records in one launch and one transfer: out[r * n + i].
+ * popdensity_to_emergence reads the same field cells on every day between release and
+ * collection (Bayes_funcs.py:60-118): one call per collection instead of one per day. */
+int ps_record_gather_multi(ps_solver* s, int nrec, const int32_t* kind, const int32_t* idx, int64_t n,
+                           const int32_t* rows, const int32_t* cols, double scale, double negval,
+                           double* out);
 /* sum_d w[d] * record(kind[d], idx[d]) -> record (PS_REC_WSUM,0)  (CalcSol.py:322) */
 int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx,
                     const double* w);

@@ -49,6 +49,17 @@ def _project(per_day, start_day, collection_day, obs_days):
     return out
 
 
+def _gather_days(modelsol, days, rows, cols):
+    '''{day: values at the cells}; one device call for all days when the model offers it.'''
+    days = list(days)
+    if not days:
+        return {}
+    if hasattr(modelsol, 'gather_days'):
+        vals = modelsol.gather_days(days, rows, cols)
+        return {day: vals[n] for n, day in enumerate(days)}
+    return {day: modelsol.gather(day, rows, cols) for day in days}
+
+
 def popdensity_to_emergence(modelsol, locinfo):
     '''Expected number of wasps per release-field grid point / sentinel field whose
     oviposition results in emergence on each observation date (Bayes_funcs.py:20-152).
@@ -58,8 +69,7 @@ def popdensity_to_emergence(modelsol, locinfo):
         collection_day = _days(locinfo.collection_datesPR[nframe])
         start_day = max(collection_day - max_incubation_time, 0)
         cells = np.asarray(locinfo.emerg_grids[nframe]).reshape(-1, 2)
-        per_day = {day: modelsol.gather(day, cells[:, 0], cells[:, 1])
-                   for day in range(start_day, collection_day)}
+        per_day = _gather_days(modelsol, range(start_day, collection_day), cells[:, 0], cells[:, 1])
         release_emerg.append(_project(per_day, start_day, collection_day, _unique_days(dframe)))
     sentinel_emerg = []
     for nframe, dframe in enumerate(locinfo.sent_DataFrames):
@@ -69,10 +79,8 @@ def popdensity_to_emergence(modelsol, locinfo):
         rows = np.concatenate([f[:, 0] for f in fields])
         cols = np.concatenate([f[:, 1] for f in fields])
         bounds = np.cumsum([0] + [len(f) for f in fields])
-        per_day = {}
-        for day in range(start_day, collection_day):
-            v = modelsol.gather(day, rows, cols)
-            per_day[day] = np.array([v[bounds[i]:bounds[i + 1]].sum() for i in range(len(fields))])
+        per_day = {day: np.array([v[bounds[i]:bounds[i + 1]].sum() for i in range(len(fields))])
+                   for day, v in _gather_days(modelsol, range(start_day, collection_day), rows, cols).items()}
         sentinel_emerg.append(_project(per_day, start_day, collection_day, _unique_days(dframe)))
     return (release_emerg, sentinel_emerg)
 
@@ -82,8 +90,10 @@ def popdensity_grid(modelsol, locinfo):
     (Bayes_funcs.py:156-179); the model holds end-of-day results.'''
     cells = np.asarray(locinfo.grid_cells)
     out = np.zeros((cells.shape[0], len(locinfo.grid_obs_datesPR)))
-    for nday, date in enumerate(locinfo.grid_obs_datesPR):
-        out[:, nday] = modelsol.gather(_days(date) - 1, cells[:, 0], cells[:, 1])
+    days = [_days(date) - 1 for date in locinfo.grid_obs_datesPR]
+    vals = _gather_days(modelsol, sorted(set(days)), cells[:, 0], cells[:, 1])
+    for nday, day in enumerate(days):
+        out[:, nday] = vals[day]
     return out
 
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     'ps_record_fetch_dense': (C.c_int, [_VP, C.c_int, C.c_int, _F64P]),
     'ps_record_gather': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int64, _I32P, _I32P, C.c_double,
                                    C.c_double, _F64P]),
+    'ps_record_gather_multi': (C.c_int, [_VP, C.c_int, _I32P, _I32P, C.c_int64, _I32P, _I32P, C.c_double,
+                                          C.c_double, _F64P]),
     'ps_weighted_sum': (C.c_int, [_VP, C.c_int, _I32P, _I32P, _F64P]),
     'ps_prof_enable': (C.c_int, [_VP, C.c_int]),
     'ps_prof_read': (C.c_int, [_VP, C.c_int, _F64P, _I64P]),

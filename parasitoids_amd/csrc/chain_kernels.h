@@ -285,6 +285,17 @@ static __global__ void k_take_half_spectrum(const double2* __restrict__ full, in
 }
 
 // out[i] = rec[rows[i]][cols[i]] * scale, zeroed below negval (thresholded-solution lookup)
+static __global__ void k_gather_points_multi(const double* const* __restrict__ recs, int N, const int* rows,
+                                             const int* cols, int64_t n, double scale, double negval, double* out) {
+  const double* rec = recs[blockIdx.y];
+  double* o = out + (int64_t)blockIdx.y * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double t = rec[(int64_t)rows[i] * N + cols[i]] * scale;
+    o[i] = (t < negval) ? 0.0 : t;
+  }
+}
+
 static __global__ void k_gather_points(const double* __restrict__ rec, int N, const int* rows,
                                 const int* cols, int64_t n, double scale, double negval, double* out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;

@@ -1468,6 +1468,37 @@ extern "C" int ps_record_gather(ps_solver* s, int kind, int idx, int64_t n, cons
   return PS_OK;
 }
 
+extern "C" int ps_record_gather_multi(ps_solver* s, int nrec, const int32_t* kind, const int32_t* idx, int64_t n,
+                                      const int32_t* rows, const int32_t* cols, double scale, double negval,
+                                      double* out) {
+  if (!s || nrec < 0 || n < 0 || (nrec > 0 && (!kind || !idx)) || (n > 0 && nrec > 0 && (!rows || !cols || !out)))
+    return ps_fail(PS_ERR_BAD_ARG, "record_gather_multi: bad arguments");
+  if (n == 0 || nrec == 0) return PS_OK;
+  PS_HIP(hipSetDevice(s->device));
+  std::vector<const double*> ptrs(nrec);
+  for (int r = 0; r < nrec; ++r) {
+    double* rec;
+    PS_TRY(get_record(s, kind[r], idx[r], &rec));
+    ptrs[r] = rec;
+  }
+  PS_TRY(check_coo(rows, cols, n, s->N, "gather point"));
+  PS_TRY(s->orow.ensure(n));
+  PS_TRY(s->ocol.ensure(n));
+  PS_TRY(s->oval.ensure((size_t)n * nrec));
+  PS_TRY(s->wptr.ensure(nrec));
+  PS_HIP(hipMemcpyAsync(s->orow.p, rows, n * 4, hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipMemcpyAsync(s->ocol.p, cols, n * 4, hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipMemcpyAsync(s->wptr.p, ptrs.data(), nrec * sizeof(double*), hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));   // ptrs is a host temporary
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_gather_points_multi, dim3(blocks, nrec), dim3(256), 0, s->stream,
+                     (const double* const*)s->wptr.p, s->N, s->orow.p, s->ocol.p, n, scale, negval, s->oval.p);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(out, s->oval.p, (size_t)n * nrec * 8, hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  return PS_OK;
+}
+
 extern "C" int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx, const double* w) {
   if (!s || n < 1 || !kind || !idx || !w) return ps_fail(PS_ERR_BAD_ARG, "weighted_sum: bad arguments");
   PS_HIP(hipSetDevice(s->device));

@@ -254,6 +254,16 @@ class HipSolve():
                                            float(scale), float(negval), L.p_f64(out)))
         return out
 
+    def gather_multi(self, kinds, idxs, rows, cols, scale=1.0, negval=1e-8):
+        '''The same cells from several records in one launch and one transfer -> [nrec, n].'''
+        k, i = L.i32(kinds), L.i32(idxs)
+        r, c = L.i32(rows), L.i32(cols)
+        out = np.empty((len(k), len(r)))
+        L.check(self._lib.ps_record_gather_multi(self._h, len(k), L.p_i32(k), L.p_i32(i), len(r),
+                                                 L.p_i32(r), L.p_i32(c), float(scale), float(negval),
+                                                 L.p_f64(out)))
+        return out
+
     def dense(self, kind, idx):
         out = np.empty((self.dom_len, self.dom_len))
         L.check(self._lib.ps_record_fetch_dense(self._h, kind, idx, L.p_f64(out)))

@@ -132,3 +132,10 @@ class PopModel():
         scale = float(self.r_number)
         kind, idx = (L.REC_STATE, 0) if day == 0 else (L.REC_CHAIN, day - 1)
         return solver.gather(kind, idx, rows, cols, scale=scale, negval=1e-8)
+
+    def gather_days(self, days, rows, cols):
+        '''gather() for several days at once -> [len(days), len(rows)] (one device call).'''
+        days = list(days)
+        kinds = [L.REC_STATE if d == 0 else L.REC_CHAIN for d in days]
+        idxs = [0 if d == 0 else d - 1 for d in days]
+        return self.solver.gather_multi(kinds, idxs, rows, cols, scale=float(self.r_number), negval=1e-8)

@@ -103,3 +103,28 @@ def test_metropolis_on_kalbar_field_data():
         logps.append(res['logp'])
         pm.close()
     assert np.array_equal(logps[0], logps[1])
+
+
+def test_gather_days_equals_per_day_gather():
+    """PopModel.gather_days (one ps_record_gather_multi call) against one ps_record_gather per
+    day: identical values, including day 0 (the state record) and repeated cells."""
+    from parasitoids_amd import hip_lib
+    from parasitoids_amd import _lib as L
+    from parasitoids_amd import synthetic
+    R, K, nd = 64, 33, 5
+    state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=11, sigma=(1.5, 3.0), shift=2.0)
+    s = hip_lib.HipSolve(state, [K, K], mode='exact')
+    s.set_kernels(kernels)
+    s.run_chain(renorm=False)
+    rng = np.random.default_rng(0)
+    rows = rng.integers(R - 20, R + 20, 300)
+    cols = rng.integers(R - 20, R + 20, 300)
+    kinds = [L.REC_STATE] + [L.REC_CHAIN] * nd
+    idxs = [0] + list(range(nd))
+    multi = s.gather_multi(kinds, idxs, rows, cols, scale=1e4, negval=1e-8)
+    assert multi.shape == (nd + 1, 300)
+    for n, (k, i) in enumerate(zip(kinds, idxs)):
+        assert np.array_equal(multi[n], s.gather(k, i, rows, cols, scale=1e4, negval=1e-8))
+    assert multi[1:].max() > 0
+    assert s.gather_multi([], [], rows, cols).shape == (0, 300)
+    s.close()
