@@ -8,11 +8,20 @@ FFT -> spectral product -> inverse FFT -> threshold statistics / boundary flag -
 resident in HBM.  N > 1: one process per GPU, every rank runs its own replica
 stack (weak scaling, no data-path collective).
 
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks
+itself (one child process per GPU, RCCL rendezvous on 127.0.0.1); under
+`torch.distributed.run` it is one of the ranks.  The launching parent never touches the GPU.
+
+Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
+  parity            device vs CPU oracle on the first days of the benchmarked stack itself,
+  exact_torus_mode  the same stack with exact reference-torus results ('auto' mode),
+  real_wind         BASELINE config 3a/3b: Carnarvon wind, R=2048, 30 days, device chain rate,
+  bayes             the second BASELINE metric: MCMC samples/hour on the Kalbar data.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,19 +33,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PROF_EVERY = 7          # co-prime with the 30 days of a stack: every day position gets sampled
 
-# algorithmic bytes per launch in units of P^2 (P = reference torus N + K//2), the
-# split of SURVEY 8d's W_day = 96 P^2 over this implementation's kernels
-ALG_P2 = {
-    'row_fwd': 16.0,     # kernel R2C row pass: 8 in + 8 out
-    'col_fwd_a': 8.0,    # first half of the kernel's forward column pass (16 P^2 in two sub-passes)
-    'col_fwd_b': 8.0,    # second half -- only the state FFT uses it unfused
-    'col_inv_a': 40.0,   # fused: kernel column sub-pass 2 (8) + spectral product (24) + inverse sub-pass 1 (8)
-    'col_inv_b': 8.0,    # inverse column sub-pass 2
-    'row_inv': 24.0,     # inverse C2R row pass (16) + epilogue read of the real field (8)
-    'refft_pred': 0.0,   # flag-conditional re-FFT launches (40 P^2 per flagged day; no-ops here)
-    # the fused pass over 2/4/8 consecutive days in one launch: col_inv_a's 40 P^2 per grid-day
-    # x the days one launch processes (the launch itself moves fewer bytes -- the intermediate
-    # state spectra stay in LDS -- which is what `traffic` shows)
+# SURVEY 8d's normative model of an UNFUSED pipeline, W_day = 96 P^2 (P = reference torus
+# N + K//2), split over this implementation's launch classes.  Reported per class as
+# `model_GBps` and for the whole chain as `alg_GBps_whole_chain`; NOT what `roofline` uses.
+MODEL_P2 = {
+    'row_fwd': 16.0, 'col_fwd_a': 8.0, 'col_fwd_b': 8.0, 'col_inv_a': 40.0, 'col_inv_b': 8.0,
+    'row_inv': 24.0, 'refft_pred': 0.0,
     'col_inv_a_x2': 80.0, 'col_inv_a_x4': 160.0, 'col_inv_a_x8': 320.0,
 }
 DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8}
@@ -46,10 +48,28 @@ PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': 'void k_col_fused<', 'col_
             'col_inv_a_x8': 'void k_col_fused_multi<false, 8,'}
 
 
+def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0):
+    """ALGORITHMIC HBM bytes of ONE launch of this implementation's kernel class: what the
+    launch has to read and write given that its intermediates stay in LDS --
+    the compulsory traffic, which the PMC counters confirm (`roofline.traffic`).
+    S = one half spectrum [fft_len][ld] complex128."""
+    ld = (fft_len // 2 + 1 + 7) // 8 * 8
+    S = fft_len * ld * 16.0
+    F = N * N * 8.0
+    nd = DAYS_PER_LAUNCH.get(cls, 1)
+    if cls.startswith('col_inv_a'):
+        # state in, state out, nd first-inverse-sub-pass outputs; the kernels' side is either
+        # their live row-pass rows (direct sum) or nd intermediate spectra
+        return (2 + nd) * S + (kernel_rows_bytes * nd if direct else nd * S)
+    return {'row_inv': S + F, 'col_inv_b': 2 * S, 'col_fwd_a': 2 * S, 'col_fwd_b': 2 * S,
+            'row_fwd': None, 'refft_pred': None}.get(cls)
+
+
 def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the latest committed rocprofv3 PMC
     summary (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE);
-    None when no summary covers the kernel."""
+    None when no summary covers the kernel.  The PMC pass is a separate rocprofv3 run
+    (scripts/hbm_traffic.py); it cannot be collected inside this process."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_pmc.json')),
@@ -66,8 +86,7 @@ def pmc_traffic(kernel_class):
     return (best['fetch_corrected_MB'] + best['write_size_MB']) * 1024 * 1024, os.path.basename(files[-1])
 
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -78,39 +97,92 @@ def parse():
     ap.add_argument('--mode', default='fast', choices=['fast', 'exact', 'fold', 'auto'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-days', type=int, default=6)   # ~10 s of one host core
-    return ap.parse_args()
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the exact_torus_mode / real_wind / bayes sub-records')
+    ap.add_argument('--rehearse', action='store_true',
+                    help='launcher/rendezvous rehearsal without device work (CPU test of the N>1 '
+                         'control flow with BENCH_BACKEND=gloo); prints value null')
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------- launcher
+def launch_ranks(n, argv, script=None):
+    """Start n ranks of this script, one per GPU, and wait for them.  Runs in a parent that has
+    made no torch.cuda / HIP call (and imports neither): children are fresh interpreters, never
+    an exec of this one.  Returns the exit code (non-zero if any rank failed)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0:
+                rc = rc or code
+                deadline = deadline or time.time() + 30     # a dead rank leaves the others in a barrier
+        if deadline and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+# --------------------------------------------------------------------------- CPU oracle leg
 def cpu_baseline(state, kernels, K, ndays_sample):
     """Oracle (CPU restatement of CalcSol.get_solutions) on a bounded sample of the
-    same workload: state FFT + `ndays_sample` day steps, scipy.fft, one thread."""
+    same workload: state FFT + `ndays_sample` day steps, scipy.fft, one thread.
+    Returns (record, raw oracle fields of those days) -- the fields are what `parity`
+    compares the device records with."""
     from oracle import calcsol as OC
     N = state.shape[0]
     ms = np.array([K, K])
     t0 = time.perf_counter()
     hat = OC.fft2(state, ms)
     t_init = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    fields = []
+    dt = 0.0
     for n in range(ndays_sample):
+        t0 = time.perf_counter()
         OC.fftconv2(hat, kernels[n].tocsr())
         A, flag = OC.ifft2(hat, [N, N])
         OC.r_small_vals(A, prob_model=True)
         if flag:
             hat = OC.fft2(A, ms)
-    dt = time.perf_counter() - t0
-    return {'value': ndays_sample / dt, 'unit': 'grid-days/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d of the %d day steps of the same stack (oracle/calcsol.py, scipy.fft c2c '
-                      'at P=%d, 1 thread; state FFT %.1fs not counted)'
-                      % (ndays_sample, len(kernels), N + K // 2, t_init),
-            'host_cpus': os.cpu_count()}
+        dt += time.perf_counter() - t0
+        fields.append(A.toarray())
+    rec = {'value': ndays_sample / dt, 'unit': 'grid-days/s', 'cores': 1, 'kind': 'port',
+           'sample': '%d of the %d day steps of the same stack (oracle/calcsol.py, scipy.fft c2c '
+                     'at P=%d, 1 thread; state FFT %.1fs not counted)'
+                     % (ndays_sample, len(kernels), N + K // 2, t_init),
+           'host_cpus': os.cpu_count()}
+    return rec, fields
 
 
+def max_abs_vs(solver, fields):
+    return float(max(np.abs(solver.dense(0, d) - f).max() for d, f in enumerate(fields)))
+
+
+# --------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ['PARASITOID_DEVICE'] = str(local)
@@ -120,24 +192,56 @@ def main():
     # BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks
     # (ranks then share devices); the driver's runs use RCCL ("nccl"), one rank per GPU.
     backend = os.environ.get('BENCH_BACKEND', 'nccl')
-    if backend != 'nccl':
-        local = local % max(1, torch.cuda.device_count())
-        os.environ['PARASITOID_DEVICE'] = str(local)
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    if not args.rehearse:
+        if backend == 'nccl' and ndev < world:
+            raise SystemExit('--gpus %d but only %d device(s) visible' % (world, ndev))
+        if backend != 'nccl':
+            local = local % max(1, ndev)
+            os.environ['PARASITOID_DEVICE'] = str(local)
+        torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
+        if backend == 'nccl' and not args.rehearse:
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local))
         else:
+            backend = backend if backend != 'nccl' else 'gloo'
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
+    on_gpu = backend == 'nccl' and not args.rehearse
+
+    def gather_times(dt):
+        """max over ranks (the contract's clock) and every rank's own time"""
+        if world == 1:
+            return dt, [dt]
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if on_gpu else 'cpu')
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per = [float(x.item()) for x in allt]
+        return max(per), per
+
+    R, K, nd = args.rad_res, args.kshape, args.ndays
+    N = 2 * R + 1
+    P = N + K // 2
+
+    if args.rehearse:
+        dist.barrier() if world > 1 else None
+        dt, per = gather_times(1.0 + 0.0 * rank)
+        if rank == 0:
+            print(json.dumps({'metric': 'grid-days/sec on 4096^2 fp64 domain', 'value': None,
+                              'unit': 'grid-days/s', 'n_gpus': dist.get_world_size() if world > 1 else 1,
+                              'steps': args.steps, 'warmup': args.warmup, 'rehearsal': True,
+                              'ranks_seen': len(per), 'backend': backend}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from parasitoids_amd import hip_lib, synthetic
 
-    R, K, nd = args.rad_res, args.kshape, args.ndays
     state, kernels, params = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613)  # same stack on every rank
-    N = 2 * R + 1
-    P = N + K // 2
     solver = hip_lib.HipSolve(state, [K, K], mode=args.mode, device=local, chain_only=True)
     solver.set_kernels(kernels)
 
@@ -184,32 +288,36 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
     prof = solver.prof_read()
     solver.prof_enable(False)
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_rank = gather_times(dt_own)
 
     if rank == 0:
-        grid_days = world * args.steps * nd
+        nranks = dist.get_world_size() if world > 1 else 1
+        grid_days = nranks * args.steps * nd
         value = grid_days / dt
         kern = {}
-        alg_p2 = dict(ALG_P2)
-        if solver.kernels_direct:
+        model_p2 = dict(MODEL_P2)
+        direct = bool(solver.kernels_direct)
+        if direct:
             # compact kernels: the first forward column sub-pass (col_fwd_a, 8 P^2 per grid-day)
             # is evaluated inside the fused launch
             for k, n in DAYS_PER_LAUNCH.items():
-                alg_p2[k] += 8.0 * n
-            alg_p2['col_inv_a'] += 8.0
+                model_p2[k] += 8.0 * n
+            model_p2['col_inv_a'] += 8.0
+        fl = solver.fft_len
+        krows = solver.kernel_rows_bytes if hasattr(solver, 'kernel_rows_bytes') else 0.0
         for k, (ms, cnt) in prof.items():
             if cnt:
                 avg = ms / cnt
-                alg = alg_p2[k] * P * P
-                kern[k] = {'avg_ms': round(avg, 4), 'timed_launches': cnt,
-                           'alg_GBps': round(alg / (avg * 1e-3) / 1e9, 1)}
+                e = {'avg_ms': round(avg, 4), 'timed_launches': cnt,
+                     'model_GBps': round(model_p2[k] * P * P / (avg * 1e-3) / 1e9, 1)}
+                b = launch_bytes(k, N, fl, direct, krows)
+                if b:
+                    e['bytes_per_launch'] = b
+                    e['hbm_GBps'] = round(b / (avg * 1e-3) / 1e9, 1)
+                kern[k] = e
         if not kern:      # BENCH_NO_PROF diagnostic run
             print(json.dumps({'value': round(value, 3), 'ms_per_step': round(dt / args.steps * 1e3, 3),
                               'note': 'HIP-event profiling disabled'}))
@@ -217,13 +325,13 @@ def main():
         # total time per class: multi-day launches are all timed, the others every PROF_EVERY-th
         dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches']
                   * (1 if k in DAYS_PER_LAUNCH else PROF_EVERY))
-        ach = kern[dom]['alg_GBps']
+        ach = kern[dom].get('hbm_GBps')
         traffic, traffic_src = pmc_traffic(dom) if (R, K, nd) == (2048, 2049, 30) else (None, None)
         out = {
             'metric': 'grid-days/sec on 4096^2 fp64 domain',
             'value': round(value, 3),
             'unit': 'grid-days/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': nranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
@@ -231,24 +339,40 @@ def main():
                                    'K=%d, reference torus P=%d, FFT size %d (%s mode), prob model, '
                                    'one replica stack per GPU' % (N, 2 * R, nd, K, P, solver.fft_len,
                                                                   args.mode),
-                       'dom_len': N, 'ndays': nd, 'kshape': K, 'P': P, 'fft_len': solver.fft_len},
+                       'dom_len': N, 'ndays': nd, 'kshape': K, 'P': P, 'fft_len': solver.fft_len,
+                       'kernels_direct': direct},
+            'per_rank_grid_days_per_s': [round(args.steps * nd / t, 2) for t in per_rank],
+            # SURVEY 8d's normative whole-chain figure: the unfused model's 96 P^2 per grid-day
+            # times the measured rate.  A model rate, not a bandwidth measurement.
             'alg_bytes_per_grid_day': 96.0 * P * P,
-            'alg_GBps_whole_chain': round(value / world * 96.0 * P * P / 1e9, 1),
-            # achieved/frac: ALGORITHMIC bytes of the unfused pipeline model per launch
-            # / launch time -- above 1 when the launch keeps intermediates in LDS; traffic and
-            # traffic_GBps: bytes the launch really moved (rocprofv3 PMC) and their rate
+            'alg_GBps_whole_chain': round(value / nranks * 96.0 * P * P / 1e9, 1),
+            # roofline of the dominant launch class: achieved = the bytes one launch of THIS
+            # kernel has to move (launch_bytes) / its HIP-event duration; frac = achieved / peak
+            # (<= 1); traffic = bytes the PMC counters saw for one launch (committed rocprofv3
+            # summary, separate run), traffic_GBps = traffic / the duration measured here
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None,
+                         'traffic': traffic,
                          'traffic_GBps': (round(traffic / (kern[dom]['avg_ms'] * 1e-3) / 1e9, 1)
                                           if traffic else None),
-                         'alg_bytes_per_launch': alg_p2[dom] * P * P, 'traffic_source': traffic_src},
+                         'traffic_frac': (round(traffic / (kern[dom]['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                          if traffic else None),
+                         'bytes_per_launch': kern[dom].get('bytes_per_launch'),
+                         'days_per_launch': DAYS_PER_LAUNCH.get(dom, 1),
+                         'avg_launch_ms': kern[dom]['avg_ms'],
+                         'traffic_source': ('profiles/%s (committed rocprofv3 --pmc summary, not '
+                                            'collected in this run)' % traffic_src) if traffic_src else None},
             'kernels': kern,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(state, kernels, K, args.cpu_days)
+        if nranks == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'], ofields = cpu_baseline(state, kernels, K, args.cpu_days)
+            # parity at the benchmarked configuration: the oracle's raw day fields against the
+            # device records of the very stack that was timed (fast mode), outside the timed region
+            par = {'days': len(ofields), 'tolerance': 1e-12,
+                   'max_abs_%s' % args.mode: max_abs_vs(solver, ofields)}
             if args.mode == 'fast':
-                # for reference: the same stack with exact reference-torus results ('auto' mode:
-                # direct transform on P, or the folded linear convolution when P is awkward)
+                # the same stack with exact reference-torus results ('auto' mode: direct
+                # transform on P, or the folded linear convolution when P is awkward)
                 solver.close()
                 s2 = hip_lib.HipSolve(state, [K, K], mode='auto', device=local, chain_only=True)
                 s2.set_kernels(kernels)
@@ -260,7 +384,20 @@ def main():
                 s2.sync()
                 out['exact_torus_mode'] = {'value': round(2 * nd / (time.perf_counter() - t1), 3),
                                            'unit': 'grid-days/s', 'mode': s2.mode, 'fft_len': s2.fft_len}
+                par['max_abs_exact_torus'] = max_abs_vs(s2, ofields)
                 s2.close()
+            par['ok'] = all(v < 1e-12 for k, v in par.items() if k.startswith('max_abs'))
+            out['parity'] = par
+            del ofields
+        if nranks == 1 and not args.no_extras and (R, K, nd) == (2048, 2049, 30):
+            solver.close()
+            import bench_extras
+            for key, fn in (('real_wind', bench_extras.real_wind_record),
+                            ('bayes', bench_extras.bayes_record)):
+                try:
+                    out[key] = fn(device=local)
+                except Exception as e:          # a sub-record must not cost the headline line
+                    out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

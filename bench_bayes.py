@@ -73,19 +73,49 @@ def main():
     ap.add_argument('--rad-res', type=int, default=400)
     ap.add_argument('--mode', default='auto', choices=['exact', 'fold', 'fast', 'auto'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rehearse', action='store_true',
+                    help='launcher/rendezvous rehearsal without device work (CPU test, gloo)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # the driver calls `python bench_bayes.py --gpus N`: start the N ranks here, from a
+        # parent that never touches the GPU (bench.launch_ranks)
+        from bench import launch_ranks
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], script=__file__))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ['PARASITOID_DEVICE'] = str(local)
     import torch
     import torch.distributed as dist
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')
+    if args.rehearse:
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'Bayes_Run model evaluations/hour (Kalbar, 18 days)', 'value': None,
+                              'n_gpus': dist.get_world_size() if world > 1 else 1, 'rehearsal': True}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if backend == 'nccl' and torch.cuda.device_count() < world:
+        raise SystemExit('--gpus %d but only %d device(s) visible' % (world, torch.cuda.device_count()))
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
+        os.environ['PARASITOID_DEVICE'] = str(local)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from parasitoids_amd import ParasitoidModel as PM
     from parasitoids_amd.pop_model import PopModel
     import warnings
@@ -111,13 +141,13 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
         out = {'metric': 'Bayes_Run model evaluations/hour (Kalbar, 18 days)',
                'value': round(world * args.evals / dt * 3600.0, 1), 'unit': 'evaluations/hour',
-               'n_gpus': world, 'evals': args.evals, 'warmup': args.warmup,
+               'n_gpus': dist.get_world_size() if world > 1 else 1, 'evals': args.evals, 'warmup': args.warmup,
                'ms_per_eval': round(dt / args.evals * 1e3, 3), 'higher_is_better': True,
                'scaling': 'weak', 'dtype': 'f64', 'data': 'kalbarwind.txt (reference data)',
                'config': {'workload': 'pop_model body: 18 x prob_mass + get_populations, R=%d '

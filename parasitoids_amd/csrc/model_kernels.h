@@ -3,11 +3,15 @@
 // the work is ~(2H+2)^2 bivariate-normal corner evaluations per period, 1440
 // periods per day.
 //
-// Layout: one dense N x N fp64 pmf per day in HBM.  Each 16 x 16 output tile is
-// owned by one workgroup that walks the day's periods in order and adds
-// hprob[t] * mass (ParasitoidModel.py:539-540) -- a gather, so the accumulation
-// order is the reference's and results are reproducible run to run (no atomics).
-// Cell masses come from a shared (TS+1)^2 grid of BVU corner values in LDS.
+// Layout: one dense N x N fp64 pmf per day in HBM, cut into 16 x 16 tiles.  Per tile the
+// ORDERED list of periods whose stamp window touches it is built first (k_tile_count ->
+// scan -> k_tile_fill: only real (tile, period) pairs are stored).  k_pair_masses gives
+// every pair its own wave: the Phi factors of the needed column/row edges, the BVU corner
+// values of the part of the tile under the window, the 256 cell masses times hprob[t]
+// (explicit __dmul_rn) -> a 2 KB record.  k_tile_accumulate adds a tile's records with
+// __dadd_rn in ascending period order (ParasitoidModel.py:539-540 -- the reference's
+// unfused accumulation order), so results are bit-identical to a sequential loop and
+// reproducible run to run: no atomics, no chain of barriers through a tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

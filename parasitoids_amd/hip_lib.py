@@ -63,13 +63,16 @@ def _create_solver(lib, handle, dev, dom_len, max_shape, mode, chain_only=False)
 class HipSolve():
     """Device-resident Fourier-space solution, cf. `cuda_lib.CudaSolve`."""
 
-    def __init__(self, A, max_shape, mode='exact', device=None, chain_only=False):
+    def __init__(self, A, max_shape, mode='auto', device=None, chain_only=False):
         '''Initialize the solver with the fft of the solution after the first day.
 
         Args:
             A: First day's spread, sparse matrix (square, N x N)
             max_shape: Shape of the largest filter (cuda_lib.py:18-28)
-            mode: 'exact' | 'fold' | 'fast' | 'auto', see `_create_solver`
+            mode: 'exact' | 'fold' | 'fast' | 'auto', see `_create_solver`.  The default 'auto'
+                  is exact reference-torus arithmetic whenever the pad can be planned and the
+                  fast size otherwise, so a `cuda_lib` shim (INTEGRATION.md section 1) never
+                  fails at construction for an awkward pad (prime factor > 1024, size > 9720)
             chain_only: the caller uses set_kernels / run_chain / records only (lets 'auto'
                   pick the fold mode, which has no per-call fftconv2 / get_cursol / back_solve)'''
         self._h = L._VP()
@@ -95,7 +98,7 @@ class HipSolve():
         self._nk = 0
 
     @classmethod
-    def from_model(cls, model, i, max_shape, mode='exact', device=None, chain_only=False):
+    def from_model(cls, model, i, max_shape, mode='auto', device=None, chain_only=False):
         '''Solver whose first-day state is day i of `model`'s last device batch, re-centred
         into the domain (Run.py:454-458) without leaving the GPU.'''
         self = cls.__new__(cls)

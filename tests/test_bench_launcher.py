@@ -1,0 +1,42 @@
+"""`python bench.py --gpus N` must start N ranks itself (the driver calls it exactly like
+that) -- exercised here on CPU through the launcher path with gloo and no device work."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *argv, env=None):
+    e = dict(os.environ, BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(argv), env=e,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus2_launches_two_ranks():
+    p = _run('bench.py', '--gpus', '2', '--rehearse')
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['rehearsal'] is True
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    # as one rank of a 3-rank torchrun job but told --gpus 2: must not silently report n_gpus 1
+    p = _run('bench.py', '--gpus', '2', '--rehearse', env={'RANK': '0', 'WORLD_SIZE': '3', 'LOCAL_RANK': '0'})
+    assert p.returncode != 0 and 'WORLD_SIZE 3 != --gpus 2' in p.stderr
+    p = _run('bench.py', '--gpus', '1', '--rehearse', env={'RANK': '0', 'WORLD_SIZE': '2', 'LOCAL_RANK': '0'})
+    assert p.returncode != 0
+
+
+def test_bench_bayes_gpus2_launches_two_ranks():
+    p = _run('bench_bayes.py', '--gpus', '2', '--rehearse')
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    assert json.loads(lines[0])['n_gpus'] == 2
