@@ -121,7 +121,7 @@ def main():
     import warnings
     warnings.simplefilter('ignore', RuntimeWarning)
 
-    wd, days = PM.get_wind_data(os.path.join(ROOT, 'tests', 'golden', 'data', 'kalbar'), 30, '00:00')
+    wd, days = PM.get_wind_data(os.path.join(ROOT, 'parasitoids_amd', 'data', 'kalbar'), 30, '00:00')
     pm = PopModel(wd, days, domain_info=(10000.0, args.rad_res), r_number=130000,
                   mode=args.mode, device=local)
     props = proposals(np.random.default_rng(1000 + rank), args.warmup + args.evals)

@@ -3,7 +3,7 @@ with, counterpart of the reference's `Data_Import.LocInfo` (same attribute names
 reference class cannot be constructed in this image: it needs openpyxl and calls
 `pd.read_excel(sheetname=...)`, which pandas 2.x rejects).
 
-Input files (`data_dir`, default tests/golden/data): the reference's plain-text geometry files
+Input files (`data_dir`, default parasitoids_amd/data): the reference's plain-text geometry files
 `<site>fields.txt`, `<site>releasegrid.txt`, and CSV exports of its xlsx sheets made by
 tests/golden/make_locinfo_fixtures.py (same cell contents, dates as ISO strings).
 
@@ -18,7 +18,7 @@ import numpy as np
 import pandas as pd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_DATA_DIR = os.path.join(os.path.dirname(_HERE), 'tests', 'golden', 'data')
+DEFAULT_DATA_DIR = os.path.join(_HERE, 'data')
 
 # the release grid is aligned with a nearby road (Data_Import.py:102-105)
 GRID_ROTATION_DEG = -33.0

@@ -11,6 +11,7 @@ libparasitoid_hip.so; nothing here falls back to a CPU implementation.
 many days in one launch sequence, which is what the GPU wants; `Run.main` uses it.
 """
 import ctypes as C
+import os
 import warnings
 from math import floor
 
@@ -21,6 +22,19 @@ from . import _lib as L
 
 # --------------------------------------------------------------------------- wind
 
+PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+def data_path(site_name, suffix='wind.txt'):
+    """`site_name` as the reference spells it ('data/kalbar', relative to the directory the
+    reference is run from, Run.py:96-138): used as given when that file exists, otherwise
+    resolved against this package, which ships the reference's data files under
+    parasitoids_amd/data/."""
+    if os.path.exists(site_name + suffix) or os.path.isabs(site_name):
+        return site_name
+    cand = os.path.join(PACKAGE_DIR, site_name)
+    return cand if os.path.exists(cand + suffix) else site_name
+
 
 def read_wind_file(site_name):
     """Reads `<site_name>wind.txt` (columns: day windx windy [% comment]).
@@ -29,7 +43,7 @@ def read_wind_file(site_name):
     sorted list of days.  Components with magnitude < 1e-4 are zeroed
     (ParasitoidModel.py:64-126)."""
     rows = []
-    with open(site_name + 'wind.txt') as fobj:
+    with open(data_path(site_name) + 'wind.txt') as fobj:
         for line in fobj:
             parts = line.split()
             if parts:
@@ -92,7 +106,7 @@ def get_wind_data(site_name, interp_num, start_time):
 def emergence_data(site_name):
     """Observed emergence counts `<site_name>emergence.txt` -> {field: {day: count}}
     (ParasitoidModel.py:28-60)."""
-    with open(site_name + 'emergence.txt') as fobj:
+    with open(data_path(site_name, 'emergence.txt') + 'emergence.txt') as fobj:
         fields = fobj.readline().split()[1:]
         em = {f: {} for f in fields}
         for line in fobj:

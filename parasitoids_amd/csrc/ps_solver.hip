@@ -185,6 +185,13 @@ struct ps_solver {
   DevBuf<const double*> wptr;
   DevBuf<double> wval;
   bool have_state = false;
+  // back_solve: partial spectra of the N x N release-day filters, keyed by content.  The
+  // reference calls back_solve with the same r_spread[:-1] on every simulated day
+  // (CalcSol.py:308-323); each filter is uploaded, scattered and transformed once per solver.
+  struct FiltKey { uint64_t h1, h2; int64_t n; };
+  std::vector<FiltKey> filt_keys;
+  DevBuf<cplx> Fhat;
+  long long filt_hits = 0, filt_misses = 0;
   // PS_MODE_FOLD: spatial state on the reference torus + linear-convolution scratch
   DevBuf<double> torus, lin, fold_rowsum;
   DevBuf<long long> fold_rowcnt;
@@ -831,7 +838,7 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   ps_dev_quiesce();
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
   s->tp_lo.release(); s->tp_hi.release();
-  s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release();
+  s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release(); s->Fhat.release();
   s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release(); s->krange.release();
   for (auto& v : s->recs)
     for (double* p : v)
@@ -1331,16 +1338,64 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
   // the back-solve statistics live in their own slots after the call; reuse slots [0,nfilt)
   PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
   PS_HIP(hipMemsetAsync(s->padmax.p, 0, (size_t)std::max(1, nfilt) * sizeof(unsigned long long), s->stream));
+  static const bool no_cache = getenv("PS_NO_FILTER_CACHE") != nullptr;   // A/B knob
+  // at most 32 cached filters, fewer when a spectrum is large (4 GB in total)
+  const size_t kMaxFilt = std::max<size_t>(4, std::min<size_t>(32, ((size_t)4 << 30) / (spec * sizeof(cplx))));
   for (int i = nfilt - 1; i >= 0; --i) {
     const int64_t o = off[i], n = off[i + 1] - o;
     PS_TRY(check_coo(row + o, col + o, n, K, "filter"));
-    PS_TRY(upload_coo(s, row + o, col + o, val + o, n));
     PS_TRY(ensure_record(s, PS_REC_BACK, i));
-    PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)K * K * sizeof(double), s->stream));
-    PS_TRY(scatter_from_device(s, s->orow.p, s->ocol.p, s->oval.p, n, s->kdense.p, K, 0));
-    PS_TRY(fwd2d_partial(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, 1));
+    // content key of the filter: two independent 64-bit hashes over (row, col, val) + length
+    ps_solver::FiltKey key{1469598103934665603ull, 0x9E3779B97F4A7C15ull, n};
+    {
+      auto mix = [&](const void* p, size_t bytes) {
+        const unsigned char* b = (const unsigned char*)p;
+        size_t q = 0;
+        for (; q + 8 <= bytes; q += 8) {
+          uint64_t w;
+          __builtin_memcpy(&w, b + q, 8);
+          key.h1 = (key.h1 ^ w) * 1099511628211ull;
+          key.h2 = (key.h2 + w) * 0xD6E8FEB86659FD93ull;
+          key.h2 ^= key.h2 >> 32;
+        }
+        for (; q < bytes; ++q) {
+          key.h1 = (key.h1 ^ b[q]) * 1099511628211ull;
+          key.h2 = (key.h2 + b[q]) * 0xD6E8FEB86659FD93ull;
+        }
+      };
+      mix(row + o, (size_t)n * 4);
+      mix(col + o, (size_t)n * 4);
+      mix(val + o, (size_t)n * 8);
+    }
+    int slot = -1;
+    if (!no_cache)
+      for (size_t q = 0; q < s->filt_keys.size(); ++q)
+        if (s->filt_keys[q].h1 == key.h1 && s->filt_keys[q].h2 == key.h2 && s->filt_keys[q].n == n) slot = (int)q;
+    const cplx* B = nullptr;
+    if (slot >= 0) {
+      ++s->filt_hits;
+      B = s->Fhat.p + (size_t)slot * spec;
+      // what fwd2d_partial leaves behind for the fused pass that consumes B
+      s->kt_direct = false;
+      s->kt_live = s->split ? RowLive{0, {0, 0, 0, 0}, nullptr} : RowLive{1, map_wrap(M, s->Pf), nullptr};
+    } else {
+      ++s->filt_misses;
+      cplx* dst = s->Bhat.p;
+      if (!no_cache) {
+        if (s->filt_keys.size() >= kMaxFilt) s->filt_keys.clear();
+        // growing Fhat keeps the cached spectra (DevBuf::ensure would drop them): size it once
+        if (!s->Fhat.p) PS_TRY(s->Fhat.ensure(spec * kMaxFilt));
+        dst = s->Fhat.p + s->filt_keys.size() * spec;
+        s->filt_keys.push_back(key);
+      }
+      PS_TRY(upload_coo(s, row + o, col + o, val + o, n));
+      PS_HIP(hipMemsetAsync(s->kdense.p, 0, (size_t)K * K * sizeof(double), s->stream));
+      PS_TRY(scatter_from_device(s, s->orow.p, s->ocol.p, s->oval.p, n, s->kdense.p, K, 0));
+      PS_TRY(fwd2d_partial(s, s->kdense.p, 0, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), dst, 1));
+      B = dst;
+    }
     double* rec = s->recs[PS_REC_BACK][i];
-    PS_TRY(conv_inv(s, s->Bhat.p, s->Chat.p, 1, rec, i, negval, stat_scale));
+    PS_TRY(conv_inv(s, B, s->Chat.p, 1, rec, i, negval, stat_scale));
     PS_TRY(refft_if_flag(s, rec, s->Chat.p, i));  // cuda_lib.py:208-214 semantics
   }
   s->last_renorm = 0;

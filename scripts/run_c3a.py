@@ -7,7 +7,7 @@ R = int(sys.argv[1]); mode = sys.argv[2]
 globalvars.fft_mode = mode
 p = Run.Params(config=None)
 p.cmd_line_chg(['--carnarvon', '--prob', 'domain_info=(10000.0,%d)' % R])
-p.site_name = os.path.join('tests/golden', p.site_name); p.OUTPUT = False
+p.site_name = os.path.join('parasitoids_amd', p.site_name); p.OUTPUT = False
 for rep in range(2):
     t0 = time.time()
     modelsol, days, ndays, t = Run.run_model(p, verbose=False)

@@ -43,7 +43,7 @@ def main():
     from parasitoids_amd.pop_model import PopModel
     rank, world = parallel.init()
     if rank == 0:
-        wd, days = PM.get_wind_data(os.path.join(ROOT, 'tests', 'golden', 'data', 'carnarvonearl'),
+        wd, days = PM.get_wind_data(os.path.join(ROOT, 'parasitoids_amd', 'data', 'carnarvonearl'),
                                     30, '00:30')
     else:
         wd, days = None, None

@@ -28,13 +28,13 @@ def main():
     ap.add_argument('--seed', type=int, default=1000)
     ap.add_argument('--synthetic', action='store_true',
                     help='observations drawn from the model on a Kalbar-like geometry instead of '
-                         'the Kalbar field data (tests/golden/data CSV fixtures)')
+                         'the Kalbar field data (parasitoids_amd/data CSV exports)')
     args = ap.parse_args()
     warnings.simplefilter('ignore', RuntimeWarning)
     from parasitoids_amd import ParasitoidModel as PM
     from parasitoids_amd import mcmc
     from parasitoids_amd.pop_model import PopModel
-    wd, days = PM.get_wind_data(os.path.join(ROOT, 'tests', 'golden', 'data', 'kalbar'), 30, '00:00')
+    wd, days = PM.get_wind_data(os.path.join(ROOT, 'parasitoids_amd', 'data', 'kalbar'), 30, '00:00')
     pm = PopModel(wd, days, domain_info=(10000.0, args.rad_res), r_number=130000, mode=args.mode)
     if args.synthetic:
         li = mcmc.synthetic_locinfo(pm, args.rad_res, seed=9)

@@ -1,0 +1,205 @@
+"""Oracle parity at the BASELINE.json configurations that had none of their own:
+
+ * config 3 -- the benchmarked N = 4097 synthetic stack itself, fast mode, far enough into the
+   chain that the 2-day and 4-day fused column passes with direct-sum kernels (the dominant
+   kernel of bench.py) are what is compared with the oracle,
+ * config 4 -- Kalbar `pop_model` body at R = 512 (its stated 1024^2 grid), 18 days,
+ * config 5 -- ensemble members drawn from the reference's priors at R = 1024, 30 Carnarvon
+   days, probability model, r_start = 0.354,
+ * config 3a/3b on real wind at R = 2048: size-independent properties (mass, flag count, sum 1
+   after renormalisation),
+ * the INTEGRATION.md section 1 shim replaying the reference's CalcSol loop literally.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from helpers import HP, DP, DLP, MU_R, NPER, recentre
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def hip_lib():
+    from parasitoids_amd import hip_lib
+    return hip_lib
+
+
+def _oracle_raw_chain(state, kernels, K, nd):
+    """raw (unthresholded) oracle fields + flags of the first nd days (CalcSol.py:191-201)"""
+    from oracle import calcsol as OC
+    N = state.shape[0]
+    ms = np.array([K, K])
+    hat = OC.fft2(state, ms)
+    out, flags = [], []
+    for n in range(nd):
+        OC.fftconv2(hat, kernels[n].tocsr())
+        A, flag = OC.ifft2(hat, [N, N])
+        out.append(A.toarray())
+        flags.append(bool(flag))
+        if flag:
+            hat = OC.fft2(A, ms)
+    return out, flags
+
+
+def test_config3_benchmarked_stack_against_oracle(hip_lib):
+    """bench.py's workload (N = 4097, K = 2049, P = 5121, fast mode on 5184): days 0-9 run as
+    speculation windows 2 + 4 + (4 of 8), i.e. through k_col_fused_multi<2> and <4> with the
+    direct-sum first column sub-pass -- against the oracle's raw fields at 1e-12."""
+    from parasitoids_amd import synthetic
+    R, K, nd = 2048, 2049, 10
+    state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=30, seed=20240613)
+    s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+    assert s.fft_len == 5184
+    s.set_kernels(kernels)                   # all 30, like the bench: same chunking and windows
+    s.prof_enable(True, every=1)
+    s.run_chain(0, 30, renorm=True)
+    st = s.chain_stats(0, 30)
+    prof = s.prof_read()
+    assert s.kernels_direct
+    assert prof['col_inv_a_x4'][1] >= 1 and prof['col_inv_a_x2'][1] >= 1     # the fused multi-day path ran
+    ref, flags = _oracle_raw_chain(state, kernels, K, nd)
+    assert not any(flags) and not any(x.flag for x in st)
+    for d in range(nd):
+        got = s.dense(0, d)
+        assert np.abs(got - ref[d]).max() < 1e-12, d
+        thr = ref[d] * (ref[d] >= 1e-8)
+        assert st[d].nnz == int((ref[d] >= 1e-8).sum())
+        assert abs(st[d].sum - thr.sum()) < 1e-12
+    s.close()
+
+
+def test_config4_pop_model_r512_against_oracle():
+    """BASELINE config 4's grid (1024^2: R = 512, N = 1025): the `Bayes_Run.pop_model` body on
+    Kalbar, 18 days -- device kernels + device chain vs oracle.get_populations on the same
+    kernels (Bayes_Run.py:204-336, CalcSol.py:205-325)."""
+    from oracle import calcsol as OC
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.pop_model import PopModel
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        pm = PopModel(wd, days, domain_info=(10000.0, 512), r_number=130000)     # default 'auto'
+        stats = pm.evaluate(HP, DP, DLP, MU_R, NPER)
+    assert len(stats) == 18
+    pmfs = [pm.model.fetch(i) for i in range(18)]
+    max_shape = np.max([p.shape for p in pmfs], axis=0)
+    ref = OC.get_populations([recentre(pmfs[0], 512).tocsr()], pmfs, days, 18, 1025, max_shape, 1,
+                             130000, lambda day: 1.0)
+    for d in range(18):
+        got = pm.population(d)
+        diff = abs(got - ref[d].tocsr())
+        assert (diff.max() if diff.nnz else 0.0) < 1e-7, d        # values reach 1.3e5: 1e-12 relative
+        assert abs(stats[d][1] - ref[d].sum()) < 1e-6 * 130000
+    pm.close()
+
+
+def test_config5_ensemble_members_against_oracle():
+    """BASELINE config 5: members drawn from the reference's priors (scripts/run_ensemble.py's
+    draw, Bayes_Run.py:102,:116-117,:129), R = 1024 (N = 2049), 30 Carnarvon days, probability
+    model, r_start = 0.354 -- the chain of each member vs oracle.get_solutions on the
+    device-built kernels (CalcSol.py:140-201)."""
+    from oracle import calcsol as OC
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.pop_model import PopModel
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    from run_ensemble import draw_members
+    R, nd = 1024, 30
+    N = 2 * R + 1
+    wd, days = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    members = draw_members(512)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        pm = PopModel(wd, days, domain_info=(10000.0, R), r_start=0.354, prob_model=True)
+        for i in (0, 300):
+            mem = members[i]
+            hp = (mem['lam'],) + HP[1:]
+            st = pm.evaluate(hp, (mem['sig_x'], mem['sig_y'], 0.253), DLP, mem['mu_r'], 30, ndays=nd)
+            pmfs = [pm.model.fetch(k) for k in range(nd)]
+            max_shape = np.max([p.shape for p in pmfs], axis=0)
+            ref = [recentre(pmfs[0], R)]
+            OC.get_solutions(ref, pmfs, days, nd, N, max_shape)
+            assert len(ref) == nd
+            for d in range(1, nd):
+                got = pm.population(d)
+                diff = abs(got - ref[d].tocsr())
+                assert (diff.max() if diff.nnz else 0.0) < 1e-12, (i, d)
+                assert got.nnz == ref[d].nnz
+                assert abs(got.sum() - 1.0) < 1e-11
+        pm.close()
+
+
+@pytest.mark.parametrize('rad_dist,mode', [(10000.0, 'fast'), (10000.0, 'auto'), (40000.0, 'fast')])
+def test_config3_real_wind_r2048_properties(rad_dist, mode):
+    """BASELINE config 3 on real wind (rad_dist 10 km, flags fire; C3b: 40 km):
+    R = 2048, 30 Carnarvon days, probability model.  Too big for the CPU oracle in test time:
+    every day is a pmf (sum 1 after renormalisation, CalcSol.py:134-135), raw mass never exceeds
+    1 and never grows, flags fire at 10 km and not at 40 km, and fast mode agrees with the
+    exact-torus mode on the flag sequence."""
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.pop_model import PopModel
+    wd, days = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        pm = PopModel(wd, days, domain_info=(rad_dist, 2048), mode=mode, prob_model=True)
+        pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=30)
+    st = pm.stats
+    assert len(st) == 29
+    prev = 1.0 + 1e-12
+    for x in st:
+        assert abs(x.sum + x.delta * x.nnz - 1.0) < 1e-11
+        assert x.sum <= prev + 1e-12          # kept mass never grows (only truncation removes any)
+        assert x.nnz > 0
+    nflag = sum(bool(x.flag) for x in st)
+    if rad_dist == 10000.0:
+        assert nflag == 19                    # both modes, measured against each other
+    else:
+        assert nflag == 0
+    pm.close()
+
+
+def test_reference_calcsol_loop_through_the_cuda_lib_shim(hip_lib, monkeypatch):
+    """`cuda_lib.CudaSolve = hip_lib.HipSolve`.  Replays the
+    reference's GPU branch of get_solutions literally (CalcSol.py:176-186: `CudaSolve(A,
+    max_shape)`, then per day `fftconv2(pmf.tocsr(), n == 0)` and `get_cursol([N, N])`) against
+    the oracle -- at a prime pad > 1024 (P = 1031), which exact mode cannot plan: the default
+    mode falls back to the fast size instead of raising inside the reference's loop."""
+    from oracle import calcsol as OC
+    from parasitoids_amd import synthetic
+    shim = types.ModuleType('cuda_lib')
+    shim.CudaSolve = hip_lib.HipSolve
+    monkeypatch.setitem(sys.modules, 'cuda_lib', shim)
+    import cuda_lib
+
+    for N, K in ((967, 129), (257, 65)):          # P = 967 + 64 = 1031 (prime); P = 289 = 17^2
+        R = N // 2
+        state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=4, seed=11, sigma=(4.0, 9.0), shift=12.0)
+        pmf_list = [None] + kernels
+        days = list(range(5))
+        max_shape = np.array([K, K])
+        dom_len = N
+        # --- reference loop, CalcSol.py:176-186 (its r_small_vals is the oracle's here) ---
+        modelsol = [state]
+        gpu_solver = cuda_lib.CudaSolve(modelsol[0], max_shape)
+        for n, day in enumerate(days[1:5]):
+            gpu_solver.fftconv2(pmf_list[n + 1].tocsr(), n == 0)
+            modelsol.append(OC.r_small_vals(
+                gpu_solver.get_cursol([dom_len, dom_len]), prob_model=True))
+        # ---
+        if N == 967:
+            assert gpu_solver.mode == 'fast' and gpu_solver.pad_shape == (1031, 1031)
+        else:
+            assert gpu_solver.mode == 'exact'
+        ref = [state]
+        OC.get_solutions(ref, pmf_list, days, 5, N, max_shape)
+        for d in range(1, 5):
+            diff = abs(modelsol[d].tocsr() - ref[d].tocsr())
+            assert (diff.max() if diff.nnz else 0.0) < 1e-12, (N, d)
+            assert modelsol[d].nnz == ref[d].nnz
+        gpu_solver.close()
