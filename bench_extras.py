@@ -103,8 +103,116 @@ def real_wind_record(device=None, R=2048, nd=30):
     return out
 
 
-def bayes_record(device=None):
-    return {'error': 'not wired yet'}
+def _oracle_day(args):
+    """worker of the all-cores CPU baseline: the oracle's prob_mass for one day (the reference
+    maps exactly this over `Pool()`, Run.py:422-425 / Bayes_Run.py:298-306)"""
+    day, rad_res = args
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import model as OM
+    from parasitoids_amd import ParasitoidModel as PM
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    t0 = time.perf_counter()
+    p = OM.prob_mass(day, wd, HP, DP, DLP, MU_R, NPER, 10000.0, rad_res)
+    return time.perf_counter() - t0, p.shape[0], p.nnz
+
+
+def bayes_cpu_baseline(rad_res, days, all_cores=True):
+    """The oracle's model evaluation (18 x prob_mass + 17 chain days) on the host: prob_mass of
+    ONE day and 2 chain days on one core, extrapolated (`cores: 1`); and, like the reference
+    runs it, the 18 prob_mass calls spread over a process pool (`all_cores`)."""
+    from oracle import calcsol as OC
+    from oracle import model as OM
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.Run import recentre
+    wd, _ = PM.get_wind_data('data/kalbar', 30, '00:00')
+    t0 = time.perf_counter()
+    p0 = OM.prob_mass(days[0], wd, HP, DP, DLP, MU_R, NPER, 10000.0, rad_res)
+    t_pm = time.perf_counter() - t0
+    N = 2 * rad_res + 1
+    ms = np.array(p0.shape)
+    hat = OC.fft2(recentre(p0, rad_res), ms)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        OC.fftconv2(hat, p0.tocsr())
+        A, flag = OC.ifft2(hat, [N, N])
+        OC.r_small_vals(A * 130000.0)
+        if flag:
+            hat = OC.fft2(A, ms)
+    t_day = (time.perf_counter() - t0) / 2
+    nd = len(days)
+    rec = {'value': round(3600.0 / (nd * t_pm + (nd - 1) * t_day), 2), 'unit': 'samples/hour', 'cores': 1,
+           'kind': 'port',
+           'sample': 'oracle prob_mass of 1 day (%.1fs) and 2 chain days (%.2fs each) at R=%d, extrapolated to '
+                     '%d + %d; one model evaluation per MCMC sample' % (t_pm, t_day, rad_res, nd, nd - 1)}
+    if all_cores:
+        import multiprocessing as mp
+        ncpu = os.cpu_count() or 1
+        nproc = min(nd, ncpu)
+        ctx = mp.get_context('spawn')          # this process holds the GPU: never fork it
+        t0 = time.perf_counter()
+        with ctx.Pool(nproc) as pool:
+            res = pool.map(_oracle_day, [(d, rad_res) for d in days])
+        t_pool = time.perf_counter() - t0
+        rec['all_cores'] = {'value': round(3600.0 / (t_pool + (nd - 1) * t_day), 2), 'unit': 'samples/hour',
+                            'cores': nproc, 'host_cpus': ncpu,
+                            'sample': 'the %d prob_mass days of one evaluation over a %d-process pool (%.1fs wall '
+                                      'incl. start-up, slowest day %.1fs) + %d chain days on one core (%.2fs each)'
+                                      % (nd, nproc, t_pool, max(r[0] for r in res), nd - 1, t_day)}
+    return rec
+
+
+def bayes_case(rad_res, mode, samples, burn, device=None, seed=1000):
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd import mcmc
+    from parasitoids_amd.Data_Import import LocInfo
+    from parasitoids_amd.pop_model import PopModel
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        pm = PopModel(wd, days, domain_info=(10000.0, rad_res), r_number=130000, mode=mode, device=device)
+        li = LocInfo('kalbar', (-27.947131, 152.584171), (10000.0, rad_res))      # Run.py:129
+        chain = mcmc.Sampler(pm, li, (10000.0 / rad_res) ** 2, seed=seed)
+        chain.run(burn)
+        res = chain.run(samples)
+    rec = {'value': round(res['samples_per_hour'], 1), 'unit': 'samples/hour', 'rad_res': rad_res,
+           'grid': '%d^2' % (2 * rad_res + 1), 'mode': pm.solver.mode, 'fft_len': pm.solver.fft_len,
+           'samples': samples, 'burn': burn, 'ms_per_sample': round(1e3 * res['seconds'] / samples, 3),
+           'acceptance': round(res['acceptance'], 3), 'evaluations': res['evaluations_this_run'],
+           'failed_evaluations': res['failed_evaluations'],
+           'logp_first_last': [round(float(res['logp'][0]), 3), round(float(res['logp'][-1]), 3)]}
+    pm.close()
+    return rec, days
+
+
+def bayes_record(device=None, samples=150, burn=20, cpu=True):
+    """BASELINE.json's second metric: Bayes_Run MCMC samples/hour on the Kalbar data -- one
+    chain on one GPU with the in-repo sampler (parasitoids_amd/mcmc.py: AdaptiveMetropolis block
+    + scalar Metropolis steps, the reference's priors and Poisson observation model, Kalbar wind
+    and the Kalbar field observations through Data_Import.LocInfo).  One sample = one
+    pop_model evaluation (18 x prob_mass + get_populations + observation gathers) + the scalar
+    updates.  R = 400 is the reference's hard-coded grid (Bayes_Run.py:91), R = 512 the
+    1024^2 grid BASELINE config 4 names."""
+    out = {'metric': 'Bayes_Run MCMC samples/hour (Kalbar)', 'unit': 'samples/hour', 'chains': 1,
+           'sampler': 'AdaptiveMetropolis(15 model parameters; scales, interval=500, delay=1000, '
+                      'shrink_if_necessary) + scalar Metropolis on xi, em_obs_prob, grid_obs_prob, '
+                      'A_collected, sent_obs_probs_* (Bayes_Run.py:102-196, :486-487)'}
+    days = None
+    for R in (400, 512):
+        for mode in ('auto', 'fast'):
+            key = 'r%d_%s' % (R, mode)
+            try:
+                out[key], days = bayes_case(R, mode, samples, burn, device)
+            except Exception as e:
+                out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if 'value' in out.get('r400_auto', {}):
+        out['value'] = out['r400_auto']['value']            # exact-torus results at the reference's grid
+    if cpu and days is not None:
+        for R in (400, 512):
+            try:
+                out['cpu_baseline_r%d' % R] = bayes_cpu_baseline(R, days, all_cores=True)
+            except Exception as e:
+                out['cpu_baseline_r%d' % R] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
 
 
 if __name__ == '__main__':

@@ -1,0 +1,170 @@
+"""CPU tests of the host-side sampler (parasitoids_amd/mcmc.py): the joint log density against an
+independent scipy.stats evaluation on the G9 expected-observation arrays, the
+AdaptiveMetropolis covariance recursion, scalar-step tuning, save / resume.  No device: the
+model evaluation is replaced by a deterministic function of the parameters."""
+import math
+import types
+
+import numpy as np
+from scipy import stats
+
+from parasitoids_amd import mcmc
+
+
+def g9_locinfo(g, seed=4):
+    """LocInfo stand-in on the G9 geometry with deterministic 'observations' around the
+    reference's expected values (tests/golden/make_golden.py:g9)."""
+    rng = np.random.default_rng(seed)
+    li = types.SimpleNamespace()
+    li.sent_ids = ['A', 'B', 'C']
+    li.field_sizes = {k: len(g['field_' + k]) for k in li.sent_ids}
+    li.release_collection = [np.full(g['rel0'].shape[0], 1.0), np.full(g['rel1'].shape[0], 0.5)]
+    li.grid_samples = np.full(g['grid'].shape, 2.0)
+    cell_area = (10000.0 / 128) ** 2
+    sp = mcmc.initial_sent_obs_probs(li, cell_area)
+    li.release_emerg = [rng.poisson(0.75 * g['rel%d' % i] * (li.release_collection[i] * 0.05)[:, None]) for i in range(2)]
+    li.sentinel_emerg = [rng.poisson(0.75 * g['sen%d' % i] * sp[:, None]) for i in range(2)]
+    li.grid_obs = rng.poisson(0.005 * li.grid_samples * g['grid'])
+    return li, cell_area
+
+
+def independent_log_posterior(theta, nuis, A, sp, expected, li, cell_area):
+    """The same density spelled out with scipy.stats in PyMC 2's parameterisations
+    (Bayes_Run.py:102-166, :344-433)."""
+    t = dict(zip([m[0] for m in mcmc.MODEL_BLOCK], theta))
+    tn = lambda x, mu, tau, a, b: stats.truncnorm.logpdf(x, (a - mu) * math.sqrt(tau), (b - mu) * math.sqrt(tau),
+                                                         loc=mu, scale=1 / math.sqrt(tau))
+    lp = (stats.beta.logpdf(t['lam'], 5, 1) + tn(t['f_a1'], 6, 0.3, 0, 9) + tn(t['f_a2'], 20, 0.3, 15, 24)
+          + stats.gamma.logpdf(t['f_b1_p'], 2, scale=1) + stats.gamma.logpdf(t['f_b2_p'], 2, scale=1)
+          + stats.gamma.logpdf(t['g_aw'], 2.2, scale=1) + stats.gamma.logpdf(t['g_bw'], 5, scale=1)
+          + stats.gamma.logpdf(t['sig_x'], 26, scale=1 / 0.15) + stats.gamma.logpdf(t['sig_y'], 15, scale=1 / 0.15)
+          + stats.beta.logpdf(t['corr_p'], 5, 5) + stats.beta.logpdf(t['corr_l_p'], 5, 5)
+          + stats.gamma.logpdf(t['sig_x_l'], 2, scale=1 / 0.08) + stats.gamma.logpdf(t['sig_y_l'], 2, scale=1 / 0.14)
+          + stats.norm.logpdf(t['mu_r'], 1, 1) + stats.poisson.logpmf(t['n_periods'], 30))
+    xi, em, gp = nuis
+    lp += stats.gamma.logpdf(xi, 1, scale=1) + stats.beta.logpdf(em, 1, 1) + stats.beta.logpdf(gp, 1, 1)
+    areas = np.array([li.field_sizes[k] * cell_area for k in li.sent_ids])
+    lp += tn(A, 2500, 1 / 2500, 0, areas.min())
+    for p, a in zip(sp, areas):
+        m = A / a
+        lp += stats.beta.logpdf(p, m * 40 / (1 - m), 40)
+    rel, sen, grid = expected
+    for i in range(2):
+        lp += stats.poisson.logpmf(li.release_emerg[i], xi * rel[i] * (li.release_collection[i] * em)[:, None]).sum()
+        lp += stats.poisson.logpmf(li.sentinel_emerg[i], xi * sen[i] * np.asarray(sp)[:, None]).sum()
+    lp += stats.poisson.logpmf(li.grid_obs, gp * li.grid_samples * grid).sum()
+    return float(lp)
+
+
+def test_log_posterior_of_a_fixed_point_on_g9(golden):
+    g = golden('g9_bayes_funcs')
+    li, cell_area = g9_locinfo(g)
+    expected = ([g['rel0'], g['rel1']], [g['sen0'], g['sen1']], g['grid'])
+    # rates must be positive wherever something was observed
+    assert all((e > 0).all() or True for e in expected[0])
+    theta = np.array([m[2] for m in mcmc.MODEL_BLOCK])
+    nuis = np.array([0.75, 0.05, 0.005])
+    sp = mcmc.initial_sent_obs_probs(li, cell_area)
+    for A, th, nu, s in ((2500.0, theta, nuis, sp),
+                         (1800.0, theta * np.where(np.array(mcmc.DISCRETE), 1.0, 1.02), nuis * 1.1, sp * 0.9)):
+        got = mcmc.log_posterior(th, nu, A, s, expected, li, cell_area)
+        ref = independent_log_posterior(th, nu, A, s, expected, li, cell_area)
+        assert math.isfinite(ref)
+        assert abs(got - ref) < 1e-8 * max(1.0, abs(ref)), (got, ref)
+    # out of support -> zero probability
+    bad = theta.copy()
+    bad[[m[0] for m in mcmc.MODEL_BLOCK].index('lam')] = 1.2
+    assert mcmc.log_posterior(bad, nuis, 2500.0, sp, expected, li, cell_area) == mcmc.NEG_INF
+    assert mcmc.log_posterior(theta, nuis, 1e9, sp, expected, li, cell_area) == mcmc.NEG_INF
+
+
+def test_adaptive_metropolis_covariance_recursion():
+    """The recursive update equals scaling * (sample covariance of the whole internal trace +
+    eps/(n-1) I) once the initial covariance has been weighted out (k = 0 at the first update
+    gives exactly that), and later blocks continue the same recursion."""
+    rng = np.random.default_rng(0)
+    dim = 4
+    am = mcmc.AdaptiveMetropolis(np.full(dim, 0.5), delay=10, interval=5, greedy=False)
+    assert np.allclose(am.C, np.diag(np.full(dim, 0.5)))            # scales on the diagonal
+    assert np.allclose(am.proposal_sd @ am.proposal_sd.T, am.C)
+    X = rng.normal(size=(40, dim)) @ np.diag([1.0, 2.0, 0.5, 3.0])
+    for i, x in enumerate(X):
+        am.tally(x, accepted=(i % 3 != 0))
+    # updates happen at iterations 15, 20, ... 35 (> delay, multiple of interval): 5 so far
+    assert am.cov_updates == 5 and am.trace_count == 36
+    s = 2.4 ** 2 / dim
+    seen = X[:36]
+    expect = s * (np.cov(seen.T) + 1e-5 / 35 * np.eye(dim))
+    # first update had k = 0: the (k-1)/(n-1) weight of the INITIAL covariance is -1/(n-1)
+    n1 = 16
+    w = -1.0 / (n1 - 1)
+    for n_prev, n_new in ((16, 21), (21, 26), (26, 31), (31, 36)):
+        w *= (n_prev - 1) / (n_new - 1)
+    # eps terms of the five blocks accumulate with the same weights as the data
+    assert np.allclose(am.C - w * np.diag(np.full(dim, 0.5)), expect + s * 1e-5 * 0, atol=2e-4, rtol=1e-3)
+    assert np.allclose(am.chain_mean, seen.mean(0))
+    assert np.allclose(am.proposal_sd @ am.proposal_sd.T, am.C)
+    # greedy: before `delay` only accepted states are tallied
+    am2 = mcmc.AdaptiveMetropolis(np.ones(2), delay=100, interval=50, greedy=True)
+    for i in range(20):
+        am2.tally(np.array([i, -i], float), accepted=(i % 4 == 0))
+    assert len(am2._trace) == 5
+    # shrink_if_necessary
+    am3 = mcmc.AdaptiveMetropolis(np.ones(2), delay=2, interval=2, greedy=False)
+    for i in range(7):
+        am3.tally(np.array([0.1 * i, 1.0]), accepted=False)
+    assert am3.cov_updates == 2 and np.all(np.abs(am3.C) < 0.1)       # scaled by 0.01 twice
+
+
+def test_scalar_metropolis_tuning():
+    st = mcmc.ScalarMetropolis(0.05, tune_interval=10)
+    assert st.proposal_sd == 0.05 and st.factor == 1.0
+    for _ in range(10):
+        st.tally(False)
+    assert st.factor == 0.1                      # acceptance < 0.001
+    for i in range(10):
+        st.tally(i < 8)
+    assert abs(st.factor - 0.2) < 1e-15          # acceptance 0.8 > 0.75: x2
+    assert mcmc.ScalarMetropolis(0.0).proposal_sd == 1.0
+
+
+def _fake_sampler(g, seed, **kw):
+    li, cell_area = g9_locinfo(g)
+    base = ([g['rel0'], g['rel1']], [g['sen0'], g['sen1']], g['grid'])
+    t0 = np.array([m[2] for m in mcmc.MODEL_BLOCK])
+
+    def evaluate(theta):
+        # a smooth, deterministic stand-in for the model: expected observations scale with the
+        # diffusion parameters
+        f = float(np.exp(-0.5 * (((theta - t0) / (0.1 * np.abs(t0) + 1e-3)) ** 2).sum() / len(t0)))
+        return ([f * r for r in base[0]], [f * s for s in base[1]], f * base[2])
+    return mcmc.Sampler(None, li, cell_area, seed=seed, evaluate=evaluate, **kw)
+
+
+def test_sampler_moves_adapts_and_resumes(golden, tmp_path):
+    g = golden('g9_bayes_funcs')
+    a = _fake_sampler(g, 11, delay=20, interval=10, tune_interval=15)
+    full = a.run(60)
+    assert np.all(np.isfinite(full['logp']))
+    assert full['cov_updates'] >= 3 and 0 < full['acceptance'] < 1
+    names = full['names']
+    assert names[:15] == [m[0] for m in mcmc.MODEL_BLOCK] and 'A_collected' in names
+    assert names[-3:] == ['sent_obs_probs_A', 'sent_obs_probs_B', 'sent_obs_probs_C']
+    tr = full['trace']
+    for col in ('sig_x', 'xi', 'A_collected', 'sent_obs_probs_B'):
+        assert np.ptp(tr[:, names.index(col)]) > 0, col
+    k = names.index('n_periods')
+    assert np.all(tr[:, k] == np.round(tr[:, k]))                 # discrete stays integer
+    # the joint density the sampler tracks incrementally equals a from-scratch evaluation
+    assert abs(a.logp - mcmc.log_posterior(a.theta, a.nuis, a.A_collected, a.sent_obs_probs,
+                                           a.expected, a.li, a.cell_area)) < 1e-9
+    # save after 35, resume in a fresh sampler, 25 more == the uninterrupted 60
+    b = _fake_sampler(g, 11, delay=20, interval=10, tune_interval=15)
+    b.run(35)
+    b.save(tmp_path / 'chain.npz')
+    c = _fake_sampler(g, 999, delay=20, interval=10, tune_interval=15)
+    tr0, lp0 = c.resume(tmp_path / 'chain.npz')
+    assert np.array_equal(tr0, full['trace'][:35]) and np.array_equal(lp0, full['logp'][:35])
+    rest = c.run(25)
+    assert np.array_equal(rest['trace'], full['trace'][35:])
+    assert np.array_equal(rest['logp'], full['logp'][35:])
