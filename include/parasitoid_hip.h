@@ -43,6 +43,12 @@ extern "C" {
                          * (set_state, set_kernels, chain_run, records); the per-call
                          * fftconv2 / get_cursol / back_solve / spectrum calls return
                          * PS_ERR_UNSUPPORTED. */
+#define PS_MODE_AUTO 3  /* exact reference-torus results by the cheapest route, chain API only: the
+                         * day chain runs on the PS_MODE_FAST torus for as long as nothing above
+                         * 1e-15 lies outside the N x N domain (then the two tori cannot differ by
+                         * more than that per day: the pad holds no dust to wrap around), and from
+                         * the first day that does it continues as PS_MODE_FOLD from the last
+                         * clean day's field.  ps_solver_auto_info tells which days ran where. */
 
 typedef struct ps_solver ps_solver;
 typedef struct ps_model ps_model;
@@ -83,6 +89,10 @@ int ps_solver_sync(ps_solver* s);
 /* measurement aid: 1 when the day kernels of the last transformed chunk were compact enough
  * for the direct-sum first column sub-pass inside the fused kernel (no separate launch) */
 int ps_solver_kernels_direct(ps_solver* s);
+/* PS_MODE_AUTO: *first_fold_day = first chain day of the last ps_chain_run that ran on the folded
+ * reference torus (-1: every day was clean and ran on the fast torus); *fold_fft = FFT size of the
+ * fold path (0 if it was never needed).  Other modes: -1 / 0. */
+int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_fft);
 
 /* CudaSolve.__init__ (cuda_lib.py:34-54) / CalcSol.fft2 (CalcSol.py:11-24):
  * state_hat = FFT2(zero-padded N x N sparse field). */

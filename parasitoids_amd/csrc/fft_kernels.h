@@ -98,6 +98,7 @@ struct RowInvArgs {
   double* rowsum;             // [N]
   long long* rowcnt;          // [N]
   unsigned long long* padmax; // bits of max(pad, 0)
+  double pad_floor;           // pad maxima at or below this are not published (0.5e-8: only what can raise the flag)
   int64_t stat_bstride;       // per-batch stride of rowsum/rowcnt (padmax: 1)
   FftProg prog;
 };
@@ -840,7 +841,7 @@ __global__ void __launch_bounds__(BIG ? 512 : 1024) k_row_inv(RowInvArgs a) {
     __syncthreads();
     double e = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) e += red[w];
-    if (sqrt(2.0 * (double)a.P * e) * a.scale < 0.5e-8) return;
+    if (sqrt(2.0 * (double)a.P * e) * a.scale < a.pad_floor) return;
   }
   __syncthreads();
   lds_fft<PS_INV, GEN, BIG>(data, tlo, thi, P, PS_MODE_ROW, a.rp, 0, pitch);
@@ -918,7 +919,7 @@ __global__ void __launch_bounds__(BIG ? 512 : 1024) k_row_inv(RowInvArgs a) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
     // only maxima that can matter for the flag (> 1e-8) are published: the read-check is a
     // global round trip at the end of every workgroup otherwise
-    if (m > 0.5e-8 && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (m > a.pad_floor && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax(pm, bits);
   }
 }

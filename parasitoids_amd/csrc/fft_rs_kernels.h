@@ -86,7 +86,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   if (pad_only) {
     double e = 0.0;
     for (int w = 0; w < NW; ++w) e += red[w];
-    if (sqrt(2.0 * (double)a.P * e) * a.scale < 0.5e-8) return;
+    if (sqrt(2.0 * (double)a.P * e) * a.scale < a.pad_floor) return;
   }
   if (j < S::T1) bfly<R1, PS_INV>(x);
   rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
     const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
     // only maxima that can matter for the flag (> 1e-8) are published: the read-check costs a
     // global round trip that would otherwise end every workgroup
-    if (m > 0.5e-8 && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (m > a.pad_floor && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax(pm, bits);
   }
 }

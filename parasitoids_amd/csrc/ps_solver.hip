@@ -120,6 +120,11 @@ void ps_dev_free(void* p) {
 
 void ps_dev_quiesce() { (void)hipDeviceSynchronize(); }
 static const int kPredGrid = 512;  // grid of the flag-conditional (usually empty) launches
+// PS_MODE_AUTO: a day is "clean" when nothing above this lies outside the N x N domain of the
+// fast torus.  Then the reference torus and the fast torus hold the same field up to that much
+// (a convolution with a pmf cannot raise the maximum of the dust it moves), so the fast chain IS
+// the exact-torus chain to <= 4 * days * kCleanEps.  FFT round-off in the pad is ~1e-18.
+static const double kCleanEps = 1e-15;
 #define PS_PROF_NCLS 10
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
        PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6, PS_PROF_COL_INV_A2 = 7,
@@ -185,6 +190,17 @@ struct ps_solver {
   DevBuf<const double*> wptr;
   DevBuf<double> wval;
   bool have_state = false;
+  // PS_MODE_AUTO (auto_exact): this solver is the fast-torus front; `child` is the fold-mode solver
+  // that takes over from the first day with anything above kCleanEps outside the domain.  The
+  // child shares this solver's stream, chain records and statistics slots' meaning (day index).
+  bool auto_exact = false;
+  double pad_floor = 0.5e-8;   // inverse row pass publishes pad maxima above this
+  ps_solver* child = nullptr;
+  bool borrowed = false;       // child: stream and chain records belong to the parent
+  bool child_kernels = false;  // child holds the current day kernels
+  int auto_first = -1;         // first day of the last chain_run that ran in the child (-1: none)
+  int auto_hint = -1;          // the same, relative to `first`, remembered for the next run
+  long long auto_runs = 0;
   // back_solve: partial spectra of the N x N release-day filters, keyed by content.  The
   // reference calls back_solve with the same r_spread[:-1] on every simulated day
   // (CalcSol.py:308-323); each filter is uploaded, scattered and transformed once per solver.
@@ -410,6 +426,7 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   a.rowsum = s->rowsum.p + (int64_t)stat_slot * s->N;
   a.rowcnt = s->rowcnt.p + (int64_t)stat_slot * s->N;
   a.padmax = s->padmax.p + stat_slot;
+  a.pad_floor = s->pad_floor;
   a.stat_bstride = s->N;
   if (full_field) {   // PS_MODE_FOLD: the whole Pf x Pf real field, statistics into scratch
     a.N = s->Pf;
@@ -734,7 +751,10 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   if (!out) return ps_fail(PS_ERR_BAD_ARG, "null output handle");
   *out = nullptr;
   if (dom_len < 1 || max_shape < 1) return ps_fail(PS_ERR_BAD_SHAPE, "dom_len=%d max_shape=%d", dom_len, max_shape);
-  if (mode != PS_MODE_EXACT && mode != PS_MODE_FAST && mode != PS_MODE_FOLD) return ps_fail(PS_ERR_BAD_ARG, "mode %d", mode);
+  if (mode != PS_MODE_EXACT && mode != PS_MODE_FAST && mode != PS_MODE_FOLD && mode != PS_MODE_AUTO)
+    return ps_fail(PS_ERR_BAD_ARG, "mode %d", mode);
+  const bool auto_exact = mode == PS_MODE_AUTO;
+  if (auto_exact) mode = PS_MODE_FAST;   // the front of an auto solver is a fast-torus solver
   PS_TRY(ps_use_device(device));
   PS_TRY(set_lds_attr());
   ps_solver* s = new ps_solver();
@@ -743,6 +763,8 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   s->M = max_shape / 2;
   s->Pref = dom_len + s->M;  // CalcSol.py:20-21, cuda_lib.py:26-28
   s->mode = mode;
+  s->auto_exact = auto_exact;
+  if (auto_exact) s->pad_floor = 0.5 * kCleanEps;
   s->Pf = mode == PS_MODE_FAST ? fast_size(s->Pref) : s->Pref;
   // fold mode: room for the whole linear convolution, P + K - 1 = N + 3 (K//2)
   if (mode == PS_MODE_FOLD) s->Pf = fast_size(s->Pref + 2 * s->M);
@@ -831,10 +853,16 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
 extern "C" int ps_solver_destroy(ps_solver* s) {
   if (!s) return PS_OK;
   (void)hipSetDevice(s->device);
-  if (s->stream) {
-    (void)hipStreamSynchronize(s->stream);
-    (void)hipStreamDestroy(s->stream);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->child) {
+    ps_solver_destroy(s->child);
+    s->child = nullptr;
   }
+  if (s->borrowed) {   // stream and chain records are the parent's
+    s->stream = nullptr;
+    for (auto& p : s->recs[PS_REC_CHAIN]) p = nullptr;
+  }
+  if (s->stream) (void)hipStreamDestroy(s->stream);
   ps_dev_quiesce();
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
   s->tp_lo.release(); s->tp_hi.release();
@@ -858,6 +886,27 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
 
 extern "C" int ps_solver_retarget(ps_solver* s, int max_shape) {
   if (!s || max_shape < 1) return ps_fail(PS_ERR_BAD_ARG, "retarget: bad arguments");
+  if (s->auto_exact) {
+    // the front only needs its FFT size to hold the new reference torus; the fold child is
+    // re-targeted when it fits and rebuilt on demand when it does not
+    const int m = max_shape / 2;
+    if (s->N + m > s->Pf)
+      return ps_fail(PS_ERR_BAD_SHAPE, "retarget: max_shape %d needs an FFT size >= %d, the solver has %d", max_shape,
+                     s->N + m, s->Pf);
+    PS_HIP(hipSetDevice(s->device));
+    PS_HIP(hipStreamSynchronize(s->stream));
+    if (s->child && ps_solver_retarget(s->child, max_shape) != PS_OK) {
+      ps_solver_destroy(s->child);
+      s->child = nullptr;
+    }
+    s->child_kernels = false;
+    s->M = m;
+    s->Pref = s->N + m;
+    s->have_state = false;
+    s->bhat_first = -1;
+    s->bhat_count = 0;
+    return PS_OK;
+  }
   if (s->mode != PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "retarget: only PS_MODE_FOLD solvers can change their torus");
   const int m = max_shape / 2;
   if (s->N + 3 * m > s->Pf)
@@ -1062,6 +1111,7 @@ static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const in
   s->bhat_first = -1;
   s->bhat_count = 0;
   s->kernels_on_device = true;
+  s->child_kernels = false;
   return PS_OK;
 }
 
@@ -1099,6 +1149,53 @@ int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, cons
     PS_HIP(hipMemcpyAsync(s->kval.p, val, tot * 8, hipMemcpyDeviceToDevice, s->stream));
   }
   return set_kernels_common(s, nk, off, kshape, nullptr);
+}
+
+// PS_MODE_AUTO: days [f, end) continue in the fold-mode child from the field the chain had
+// before day f (record f-1, or the first-day state), on this solver's stream and into this
+// solver's records.  Whatever the front enqueued for days >= f is overwritten in stream order.
+static int auto_handover(ps_solver* s, int first, int f, int end, double negval, double stat_scale, int renorm) {
+  if (!s->child) {
+    ps_solver* c = nullptr;
+    PS_TRY(ps_solver_create(&c, s->device, s->N, 2 * s->M + 1, PS_MODE_FOLD));
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+    c->stream = s->stream;
+    c->borrowed = true;
+    s->child = c;
+    s->child_kernels = false;
+  }
+  ps_solver* c = s->child;
+  if (!s->child_kernels) {
+    PS_TRY(ps_chain_adopt_device_kernels(c, s->nk, s->koff.data(), s->kshape.data(), s->krow.p, s->kcol.p, s->kval.p));
+    // the front may know tighter live-row ranges (host COO rows) than the whole K_d box
+    c->hkrange = s->hkrange;
+    PS_HIP(hipMemcpyAsync(c->krange.p, c->hkrange.data(), c->hkrange.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PS_HIP(hipStreamSynchronize(c->stream));
+    s->child_kernels = true;
+  }
+  const double* prev = nullptr;
+  if (f > 0 && f - 1 < (int)s->recs[PS_REC_CHAIN].size() && s->recs[PS_REC_CHAIN][f - 1] && (f > first || first > 0))
+    prev = s->recs[PS_REC_CHAIN][f - 1];
+  else if (f == first && first == 0 && !s->recs[PS_REC_STATE].empty())
+    prev = s->recs[PS_REC_STATE][0];
+  if (!prev) return ps_fail(PS_ERR_STATE, "auto mode: no field to continue day %d from", f);
+  PS_TRY(c->torus.ensure((size_t)c->Pref * c->Pref));
+  PS_HIP(hipMemsetAsync(c->torus.p, 0, (size_t)c->Pref * c->Pref * sizeof(double), c->stream));
+  PS_HIP(hipMemcpy2DAsync(c->torus.p, (size_t)c->Pref * sizeof(double), prev, (size_t)s->N * sizeof(double),
+                          (size_t)s->N * sizeof(double), (size_t)s->N, hipMemcpyDeviceToDevice, c->stream));
+  c->have_state = true;
+  auto& cr = c->recs[PS_REC_CHAIN];
+  if ((int)cr.size() < end) cr.resize(end, nullptr);
+  for (int d = f; d < end; ++d) {
+    PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
+    cr[d] = s->recs[PS_REC_CHAIN][d];
+  }
+  PS_TRY(ps_chain_run(c, f, end - f, negval, stat_scale, renorm));
+  s->auto_first = f;
+  s->auto_hint = f - first;
+  s->have_state = false;   // the front's spectrum is void now: per-call API needs a new state
+  return PS_OK;
 }
 
 extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_scale,
@@ -1170,6 +1267,20 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   }
   s->spec_window = 2;   // 2 + 4 + 8 = one chunk of 14 days, all of them in multi-day fused passes
   if (getenv("PS_NO_SPECULATION")) s->speculate = false;
+  // PS_MODE_AUTO: always speculate, with "clean" (nothing above kCleanEps outside the domain)
+  // in the role of "no flag"; the first unclean day hands the rest of the chain to the fold path.
+  // A solver whose previous run was unclean from its very first day skips the front (and looks
+  // again every 16th run: the parameters may have moved).
+  const double flag_thr = s->auto_exact ? kCleanEps : 1e-8;
+  int hint_abs = -1;
+  if (s->auto_exact) {
+    s->speculate = true;
+    s->auto_first = -1;
+    ++s->auto_runs;
+    if (count > 0 && s->auto_hint == 0 && s->auto_runs % 16 != 0)
+      return auto_handover(s, first, first, first + count, negval, stat_scale, renorm);
+    if (s->auto_hint > 0) hint_abs = first + s->auto_hint;
+  }
   if (s->speculate) {
     for (int i = 0; i < 2; ++i)
       if (!s->spec_ev[i]) PS_HIP(hipEventCreateWithFlags(&s->spec_ev[i], hipEventDisableTiming));
@@ -1209,8 +1320,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
         break;
       }
       static const size_t depth = getenv("PS_SPEC_DEPTH") ? (size_t)atoi(getenv("PS_SPEC_DEPTH")) : 2;
-      while (q.size() < depth && d < c0 + cn) {
-        const int w = std::min(s->spec_window, c0 + cn - d);
+      // auto mode: stop enqueueing right after the day that was the first unclean one last time
+      // until its check is in -- the days behind it are likely to be redone by the fold path
+      while (q.size() < depth && d < c0 + cn && !(hint_abs >= 0 && d == hint_abs + 1 && !q.empty())) {
+        int w = std::min(s->spec_window, c0 + cn - d);
+        if (hint_abs >= d) w = std::min(w, hint_abs - d + 1);
         // inside a window no flag is expected: days go through the fused pass in groups
         for (int i = 0; i < w;) {
           int g = 0;
@@ -1247,10 +1361,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       for (int i = 0; i < x.w && f < 0; ++i) {
         double m;
         __builtin_memcpy(&m, &s->hflags[x.d0 + i], sizeof(double));
-        if (m > 1e-8) f = x.d0 + i;
+        if (m > flag_thr) f = x.d0 + i;
       }
       if (f < 0) continue;
       q.clear();   // whatever was enqueued after day f is void; stream order keeps it harmless
+      if (s->auto_exact) return auto_handover(s, first, f, first + count, negval, stat_scale, renorm);
       PS_TRY(fwd2d(s, s->recs[PS_REC_CHAIN][f], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf),
                    s->Ahat.p, 1, nullptr));
       if (d - f - 1 > 0)
@@ -1265,6 +1380,16 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
 extern "C" int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out) {
   if (!s || !out || first < 0 || count < 0 || first + count > s->nstat) return ps_fail(PS_ERR_BAD_ARG, "chain_stats: bad range");
   PS_HIP(hipSetDevice(s->device));
+  if (s->auto_exact && s->child && s->auto_first >= 0 && first + count > s->auto_first) {
+    // days from auto_first on ran in the fold-mode child (same day indices)
+    const int split = std::max(first, s->auto_first);
+    if (split > first) {
+      PS_TRY(finalize_days(s, first, split - first, s->last_renorm));
+      PS_HIP(hipStreamSynchronize(s->stream));
+      PS_HIP(hipMemcpy(out, s->dstats.p + first, (size_t)(split - first) * sizeof(DayStats), hipMemcpyDeviceToHost));
+    }
+    return ps_chain_stats(s->child, split, first + count - split, out + (split - first));
+  }
   PS_TRY(finalize_days(s, first, count, s->last_renorm));
   PS_HIP(hipStreamSynchronize(s->stream));
   static_assert(sizeof(ps_day_stats) == sizeof(DayStats), "stats layout");
@@ -1651,6 +1776,13 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
 }
 
 extern "C" int ps_solver_kernels_direct(ps_solver* s) { return s && s->kt_direct ? 1 : 0; }
+
+extern "C" int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_fft) {
+  if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
+  if (first_fold_day) *first_fold_day = s->auto_exact ? s->auto_first : -1;
+  if (fold_fft) *fold_fft = s->child ? s->child->Pf : 0;
+  return PS_OK;
+}
 
 int ps_solver_dom_len_internal(ps_solver* s) { return s->N; }
 int ps_solver_device_internal(ps_solver* s) { return s->device; }

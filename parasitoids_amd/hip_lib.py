@@ -37,9 +37,13 @@ def _create_solver(lib, handle, dev, dom_len, max_shape, mode, chain_only=False)
       'fold'   the same torus, computed as a linear convolution on a fast FFT size >= P + K - 1
                and folded back modulo P -- chain API only;
       'fast'   a convenient FFT size >= P (pad-region dust lives on a different torus);
-      'auto'   exact when P is 7-smooth (cheap), else fold when the caller only needs the chain
-               API (`chain_only`), else exact; fast if none of them can be planned.
-    Returns the mode actually used."""
+      'auto'   exact reference-torus results by the cheapest route: exact when P is 7-smooth
+               (cheap); else, when the caller only needs the chain API (`chain_only`), the
+               library's PS_MODE_AUTO -- the chain runs on the fast torus while nothing above
+               1e-15 lies outside the domain (then the tori cannot differ) and continues on the
+               folded reference torus from the first day that does; else exact; fast if none of
+               them can be planned.
+    Returns the mode actually used ('auto' = PS_MODE_AUTO)."""
     if mode not in ('exact', 'fold', 'fast', 'auto'):
         raise ValueError("mode must be 'exact', 'fold', 'fast' or 'auto'")
     order = {'exact': ['exact'], 'fold': ['fold'], 'fast': ['fast']}.get(mode)
@@ -48,8 +52,8 @@ def _create_solver(lib, handle, dev, dom_len, max_shape, mode, chain_only=False)
         if _smooth7(P) or not chain_only:
             order = ['exact', 'fast']
         else:
-            order = ['fold', 'exact', 'fast']
-    code = {'exact': L.MODE_EXACT, 'fold': L.MODE_FOLD, 'fast': L.MODE_FAST}
+            order = ['auto', 'fold', 'exact', 'fast']
+    code = {'exact': L.MODE_EXACT, 'fold': L.MODE_FOLD, 'fast': L.MODE_FAST, 'auto': L.MODE_AUTO}
     rc = L.PS_OK
     for m in order:
         rc = lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, code[m])
@@ -118,8 +122,8 @@ class HipSolve():
         return self
 
     def retarget(self, max_shape):
-        '''fold mode: move the solver to another kernel shape limit / reference torus, keeping
-        its FFT size, plans and buffers (the state has to be set again)'''
+        '''fold / auto mode: move the solver to another kernel shape limit / reference torus,
+        keeping its FFT size, plans and buffers (the state has to be set again)'''
         ms = int(np.array(max_shape).ravel()[0])
         L.check(self._lib.ps_solver_retarget(self._h, ms))
         self.pad_shape = (self.dom_len + ms // 2, self.dom_len + ms // 2)
@@ -274,6 +278,14 @@ class HipSolve():
 
     def sync(self):
         L.check(self._lib.ps_solver_sync(self._h))
+
+    def auto_info(self):
+        '''PS_MODE_AUTO: (first chain day of the last run_chain that ran on the folded reference
+        torus, or -1 when every day was clean and ran on the fast torus; FFT size of the fold
+        path, 0 if it was never needed)'''
+        a, b = C.c_int32(-1), C.c_int32(0)
+        L.check(self._lib.ps_solver_auto_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     @property
     def kernels_direct(self):

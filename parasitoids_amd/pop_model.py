@@ -63,10 +63,12 @@ class PopModel():
         if s is None and self.mode in ('auto', 'fold'):
             # a cached fold-mode solver whose FFT size has room for this torus is re-targeted
             # (same plans and buffers) instead of building a new one for every kernel shape
-            need = N + 3 * (key // 2)
             for k in list(self._solvers):
                 c = self._solvers[k]
-                if c.mode == 'fold' and need <= c.fft_len <= 1.15 * need:
+                # fold: the FFT holds the whole linear convolution; auto: its fast-torus front
+                # only has to hold the reference torus (the fold child follows or is rebuilt)
+                need = N + (3 if c.mode == 'fold' else 1) * (key // 2)
+                if c.mode in ('fold', 'auto') and need <= c.fft_len <= 1.15 * need:
                     s = self._solvers.pop(k)
                     s.retarget(key)
                     break

@@ -72,7 +72,7 @@ def test_spectrum_roundtrip(hip_lib, two_arrays):
 
 
 @pytest.mark.parametrize('R,mode', [(128, 'exact'), (200, 'exact'), (128, 'fast'), (200, 'fast'),
-                                    (128, 'fold'), (200, 'fold')])
+                                    (128, 'fold'), (200, 'fold'), (128, 'auto'), (200, 'auto')])
 def test_get_solutions_chain(hip_lib, golden, R, mode):
     '''G6: CalcSol.get_solutions on Kalbar kernels.  R=128: P=364=4*7*13 (no flags);
     R=200: P=573=3*191 (generic radix, flags fire on 16 of 17 days).'''
@@ -88,14 +88,23 @@ def test_get_solutions_chain(hip_lib, golden, R, mode):
     modelsol = [first]
     OC.get_solutions(modelsol, pmfs, list(range(nd)), nd, N, ms, trace=trace)
 
-    solver = hip_lib.HipSolve(first, ms, mode=mode)
+    solver = hip_lib.HipSolve(first, ms, mode=mode, chain_only=(mode == 'auto'))
     assert solver.pad_shape == (N + ms[0] // 2, N + ms[1] // 2)
+    if mode == 'auto':       # PS_MODE_AUTO: fast torus while clean, folded reference torus after
+        assert solver.mode == 'auto' and solver.fft_len >= N + ms[0] // 2
     if mode == 'fold':       # linear convolution on a fast size, folded back onto the reference torus
         assert solver.fft_len >= N + 3 * (ms[0] // 2) and solver.mode == 'fold'
     solver.set_kernels(pmfs[1:])
     solver.run_chain(0, nd - 1, negval=1e-8, scale=1.0, renorm=True)
     stats = solver.chain_stats(0, nd - 1)
-    exact = mode in ('exact', 'fold')         # both on the reference torus
+    exact = mode in ('exact', 'fold', 'auto')         # all on the reference torus
+    if mode == 'auto':
+        # the hand-over happens on the first day with anything above 1e-15 outside the domain:
+        # at or before the first flagged day, and the later days ran on the fold path
+        f, fold_fft = solver.auto_info()
+        flags = [bool(v) for v in g[tag + '_flags'][:nd - 1]]
+        if any(flags):
+            assert 0 <= f <= flags.index(True) and fold_fft >= N + 3 * (ms[0] // 2)
     tol = ATOL if exact else 5e-8             # fast mode: pad-region semantics differ
     pos = g[tag + '_pos']
     for n in range(nd - 1):
@@ -242,8 +251,9 @@ def test_random_small_chains_against_oracle(hip_lib):
         ref = [state]
         trace = {}
         OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, ms, trace=trace)
-        for mode in ('exact', 'fold'):            # direct transform on P / linear convolution folded onto P
-            s = hip_lib.HipSolve(state, ms, mode=mode)
+        # direct transform on P / linear convolution folded onto P / fast torus while clean, then fold
+        for mode in ('exact', 'fold', 'auto'):
+            s = hip_lib.HipSolve(state, ms, mode=mode, chain_only=(mode == 'auto'))
             s.set_kernels(kernels)
             s.run_chain(renorm=True)
             st = s.chain_stats(0, nd)
@@ -256,3 +266,44 @@ def test_random_small_chains_against_oracle(hip_lib):
             s.close()
         checked_flags += int(any(trace['flags']))
     assert checked_flags >= 5
+
+
+def test_auto_mode_routes(hip_lib):
+    """PS_MODE_AUTO: a chain whose mass stays away from the boundary never leaves the fast torus
+    (and equals the exact torus to round-off); one that reaches it hands over to the fold path
+    on the first unclean day; a second run of the same solver goes straight there (hint) with
+    identical results; stats of clean and folded days come back through one call."""
+    from parasitoids_amd import synthetic
+    R, K, nd = 150, 101, 10
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(3.0, 6.0), shift=4)
+    ms = np.array([K, K])
+    for start, expect_fold in ((150, False), (262, True)):
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        ref = [state]
+        trace = {}
+        OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, ms, trace=trace)
+        s = hip_lib.HipSolve(state, ms, mode='auto', chain_only=True)
+        assert s.mode == 'auto'
+        s.set_kernels(kernels)
+        outs = []
+        for rep in range(3):
+            if rep:
+                s.set_state(state)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            f, fold_fft = s.auto_info()
+            if expect_fold:
+                assert 0 <= f <= [bool(v) for v in trace['flags']].index(True)
+                assert fold_fft >= N + 3 * (K // 2)
+            else:
+                assert f == -1 and fold_fft == 0 and not any(trace['flags'])
+            for d in range(nd):
+                np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13)
+                assert bool(st[d].flag) == bool(trace['flags'][d])
+                got = s.chain_solution(d, st[d]).tocsr()
+                assert abs(got - ref[d + 1].tocsr()).max() < 1e-12
+            outs.append([s.dense(0, d) for d in range(nd)])
+        for d in range(nd):      # run 2 and 3 both start from the remembered hint: identical
+            assert np.array_equal(outs[1][d], outs[2][d])
+        s.close()
