@@ -59,7 +59,7 @@ def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0):
     nd = DAYS_PER_LAUNCH.get(cls, 1)
     if cls.startswith('col_inv_a'):
         # state in, state out, nd first-inverse-sub-pass outputs; the kernels' side is either
-        # their live row-pass rows (direct sum) or nd intermediate spectra
+        # their live row-pass rows (direct sum / full-column pipeline) or nd intermediate spectra
         return (2 + nd) * S + (kernel_rows_bytes * nd if direct else nd * S)
     return {'row_inv': S + F, 'col_inv_b': 2 * S, 'col_fwd_a': 2 * S, 'col_fwd_b': 2 * S,
             'row_fwd': None, 'refft_pred': None}.get(cls)
@@ -299,7 +299,7 @@ def main():
         value = grid_days / dt
         kern = {}
         model_p2 = dict(MODEL_P2)
-        direct = bool(solver.kernels_direct)
+        direct = bool(solver.kernels_direct) or bool(solver.full_column)
         if direct:
             # compact kernels: the first forward column sub-pass (col_fwd_a, 8 P^2 per grid-day)
             # is evaluated inside the fused launch
@@ -340,7 +340,7 @@ def main():
                                    'one replica stack per GPU' % (N, 2 * R, nd, K, P, solver.fft_len,
                                                                   args.mode),
                        'dom_len': N, 'ndays': nd, 'kshape': K, 'P': P, 'fft_len': solver.fft_len,
-                       'kernels_direct': direct},
+                       'kernels_direct': bool(solver.kernels_direct), 'full_column_pipeline': bool(solver.full_column)},
             'per_rank_grid_days_per_s': [round(args.steps * nd / t, 2) for t in per_rank],
             # SURVEY 8d's normative whole-chain figure: the unfused model's 96 P^2 per grid-day
             # times the measured rate.  A model rate, not a bandwidth measurement.

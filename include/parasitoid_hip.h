@@ -89,6 +89,10 @@ int ps_solver_sync(ps_solver* s);
 /* measurement aid: 1 when the day kernels of the last transformed chunk were compact enough
  * for the direct-sum first column sub-pass inside the fused kernel (no separate launch) */
 int ps_solver_kernels_direct(ps_solver* s);
+/* measurement aid: 1 when the solver runs the full-column pipeline (column-major spectra, one
+ * pass per column transform: register-resident FFT sizes in PS_MODE_FAST), 0 for the tiled
+ * two-sub-pass column kernels */
+int ps_solver_pipeline(ps_solver* s);
 /* PS_MODE_AUTO: *first_fold_day = first chain day of the last ps_chain_run that ran on the folded
  * reference torus (-1: every day was clean and ran on the fast torus); *fold_fft = FFT size of the
  * fold path (0 if it was never needed).  Other modes: -1 / 0. */

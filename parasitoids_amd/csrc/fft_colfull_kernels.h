@@ -1,0 +1,123 @@
+// Full-column passes on the register-resident three-stage transform of fft_rs.h -- the
+// "column-major spectrum" pipeline for FFT sizes L = 16 * R2 * R3.
+//
+// The tiled column passes of fft_kernels.h split a length-L column transform into two sub-passes
+// (L = L1 * L2, a [L2 x W] tile per workgroup) because a [L x 8] complex128 tile does not fit in
+// LDS: every 2-D transform streams the half spectrum three times.  Here the half spectrum is
+// kept COLUMN-MAJOR ("T layout": [H columns][L], a column is 16 L contiguous bytes) and one
+// workgroup transforms ONE whole column with the data in registers (LDS is only the exchange
+// medium between the three stages, 8.5 L bytes), so a column transform is a single pass:
+//
+//   k_colfull mode 0 (day step):  kernel column (row-pass output, live rows only) -> forward
+//       FFT -> x state column (product stored back: CalcSol.py:66) -> inverse FFT -> the
+//       spatial-row intermediate the inverse row pass reads, row-major [L][ld]
+//   mode 1 (state transform):     row-pass output column -> forward FFT -> state column
+//   mode 2 (get_cursol):          state column -> inverse FFT -> row-major intermediate
+//   mode 3 (fftconv2):            state column *= FFT(kernel column)
+//
+// Per day step the spectrum-sized traffic is: state in, state out, intermediate out (3 S) instead
+// of kernel-intermediate in/out + state in/out + two intermediates (6-7 S) -- the second inverse
+// column sub-pass and the kernel's first forward column sub-pass do not exist.
+//
+// The row-major intermediate is written 16 bytes per row and column.  Eight adjacent columns
+// complete a 128-byte line; their workgroups are consecutive blocks of ONE XCD (blocks go to the
+// eight XCDs round-robin), so the line is assembled in that XCD's L2 before it goes to HBM
+// (measured with scripts/microbench/scatter_write.hip: 3.4 TB/s against 1.4 TB/s for the naive
+// block order; a tiled pass writing full lines with the same row stride reaches 2.9-3.3).
+#pragma once
+#include "fft_rs_kernels.h"
+
+struct ColFullArgs {
+  const cplx* src;       // T layout [H][L]: row-pass output of the kernel (modes 0, 3) / of the state (mode 1)
+  int64_t src_bstride;   // per blockIdx.y
+  cplx* state;           // T layout [H][L]
+  int64_t state_bstride;
+  cplx* dst;             // row-major [L][ld] (modes 0, 2)
+  int64_t dst_bstride;
+  int ld, ncols, mode, store_prod;
+  RowLive live;          // rows of src that were never written (known zero)
+  const unsigned long long* pred;
+  FftProg prog;          // the length-L row plan (its two-level twiddle table)
+};
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs a) {
+  using S = Rs<R1, R2, R3>;
+  constexpr int L = S::L;
+  if (pred_skip(a.pred)) return;
+  // block -> column: blocks b, b+8, ..., b+56 (one XCD, dispatched back to back) own the eight
+  // columns of one 128-byte line of the row-major output
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
+  if (c >= a.ncols) return;   // whole workgroup: no barrier is pending
+  double* ex = reinterpret_cast<double*>(ps_lds_raw);
+  const int j = threadIdx.x;
+  const FftProg& P = a.prog;
+  const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
+  const cplx w3 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
+  cplx x[S::RMAX];
+  cplx* st = a.state + (int64_t)blockIdx.y * a.state_bstride + (int64_t)c * L;
+  if (a.mode != 2) {
+    const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)c * L;
+    if (j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) {
+        const int n = j + q * S::T1;
+        x[q] = make_double2(0.0, 0.0);
+        if (row_live(a.live, n, blockIdx.y)) x[q] = sc[n];
+      }
+      bfly<R1, PS_FWD>(x);
+    }
+    rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);   // thread j < T3: X[j + q T3]
+    if (a.mode == 1) {
+      if (j < S::T3) {
+#pragma unroll
+        for (int q = 0; q < R3; ++q) st[j + q * S::T3] = x[q];
+      }
+      return;
+    }
+    if (j < S::T3) {
+      cplx sv[R3];
+#pragma unroll
+      for (int q = 0; q < R3; ++q) sv[q] = st[j + q * S::T3];
+#pragma unroll
+      for (int q = 0; q < R3; ++q) {
+        x[q] = cmul(sv[q], x[q]);
+        if (a.store_prod) st[j + q * S::T3] = x[q];
+      }
+    }
+    if (a.mode == 3) return;
+    // natural order (j + q T3) -> first-stage input order (j + q T1), real parts then imaginary
+    __syncthreads();
+    if (j < S::T3) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].x;
+    }
+    __syncthreads();
+    if (j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) x[q].x = ex[j + q * S::T1];
+    }
+    __syncthreads();
+    if (j < S::T3) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].y;
+    }
+    __syncthreads();
+    if (j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) x[q].y = ex[j + q * S::T1];
+    }
+    __syncthreads();
+  } else if (j < S::T1) {
+#pragma unroll
+    for (int q = 0; q < R1; ++q) x[q] = st[j + q * S::T1];
+  }
+  if (j < S::T1) bfly<R1, PS_INV>(x);
+  rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);     // thread j < T3: spatial rows j + q T3
+  if (j < S::T3) {
+    cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + c;
+#pragma unroll
+    for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * a.ld] = x[q];
+  }
+}

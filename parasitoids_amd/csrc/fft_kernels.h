@@ -60,6 +60,7 @@ struct RowFwdArgs {
   cplx* dst;
   int64_t dst_bstride;
   int H, ld, P;  // dst is [P][ld], H valid columns
+  int tstride;   // != 0 (register-resident kernels only): dst is column-major [H][tstride] (fft_colfull_kernels.h)
   int rp;        // row pairs per block
   int skip_zero;  // all-zero row pairs are not written (the next pass knows they are zero)
   const int* rowrange;  // device [batch][2] inclusive live source-row range, or nullptr
@@ -493,18 +494,168 @@ __device__ __forceinline__ void kt_direct_fill(const ColFusedArgs& a, cplx* data
   }
 }
 
+// ---- paired direct fill (k_col_fused_multi, G == 2) -------------------------------------------
+// The two outer indices of a workgroup are a CONJUGATE pair (o, L1 - o): w_L1^{j (L1 - o)} =
+// conj(w_L1^{j o}), so with v = R[i + L2 j] and w = w_L1^{j o} the four real sums
+//   S1 = sum vx wx,  S2 = sum vy wy,  S3 = sum vx wy,  S4 = sum vy wx
+// give BOTH outputs:  Y_o = (S1 - S2, S3 + S4),  Y_{L1-o} = (S1 + S2, S4 - S3)  --  four FMAs
+// per term instead of two complex multiply-adds (twelve operations).  The self-conjugate indices
+// 0 and L1/2 form the pair oq == 0, which takes the generic two-table route.
+// `ent[i * ND + day]` (LDS, built once per workgroup by fused_prologue) holds the live terms of
+// tile row i for that day's kernel: jA | nA << 8 | jB << 16 | nB << 24 -- terms j = jA .. jA+nA-1
+// (rows below the kernel centre, torus rows [0, n1)) and jB .. jB+nB-1 (wrapped rows [lo2, N)).
+__device__ __forceinline__ int pair_o(int oq, int g, int L1) { return g == 0 ? oq : (oq == 0 ? (L1 >> 1) : L1 - oq); }
+
+__device__ __forceinline__ unsigned kt_direct_entry(const ColFusedArgs& a, int i, int lo, int hi) {
+  const int L = a.L2, N = a.L1 * a.L2;
+  const SrcMap& m = a.live.map;
+  int x0[2] = {0, 1}, x1[2] = {N - 1, 0};
+  if (a.live.on) {
+    x0[0] = max(0, lo - m.off1);
+    x1[0] = min(m.n1 - 1, hi - m.off1);
+    x0[1] = max(m.lo2, lo - m.off2 + m.lo2);
+    x1[1] = min(N - 1, hi - m.off2 + m.lo2);
+  }
+  unsigned e = 0;
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const int j0 = x0[seg] <= i ? 0 : ps_div(x0[seg] - i + L - 1, a.mgL2);
+    const int j1 = x1[seg] < i ? -1 : ps_div(x1[seg] - i, a.mgL2);
+    const int cnt = max(0, j1 - j0 + 1);
+    e |= ((unsigned)(j0 & 255) | ((unsigned)cnt << 8)) << (16 * seg);
+  }
+  return e;
+}
+
+template <int ND>
+__device__ __forceinline__ void kt_direct_fill_pair(const ColFusedArgs& a, cplx* data, const cplx* stw, const cplx* wj,
+                                                    int c0, int psh, const unsigned* ent, bool conj_pair) {
+  constexpr int NDSH = ND == 1 ? 0 : (ND == 2 ? 1 : (ND == 4 ? 2 : 3));
+  constexpr int JB = 8, EL = 2;   // up to EL * JB row loads in flight per thread
+  const int L = a.L2, W = 1 << a.wsh, WN = W << NDSH;
+  const int totn = L << (a.wsh + NDSH);
+  const int nthr = blockDim.x;
+  const unsigned strideJ = (unsigned)__umul24(L, a.ld);   // elements between consecutive terms
+  const int gstep = 1 << (a.wsh + NDSH);                   // tile columns between the pair's halves
+  for (int idx0 = threadIdx.x; idx0 < totn; idx0 += EL * nthr) {
+    int row[EL], nA[EL], jA[EL], jBp[EL], T[EL], slot[EL];
+    unsigned baseA[EL], baseB[EL];
+    const cplx* src[EL];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const int idx = idx0 + e * nthr;
+      const int i = idx >> (a.wsh + NDSH), cc = idx & (WN - 1);
+      const int day = cc >> a.wsh, c = cc & (W - 1), col = c0 + c;
+      row[e] = i;
+      slot[e] = idx < totn ? (i << psh) + (day << a.wsh) + c : -1;
+      nA[e] = 0; jA[e] = 0; jBp[e] = 0; T[e] = 0; baseA[e] = 0; baseB[e] = 0;
+      src[e] = a.src;
+      if (idx < totn && col < a.ncols) {
+        const unsigned en = ent[i * ND + day];
+        jA[e] = (int)(en & 255u);
+        nA[e] = (int)((en >> 8) & 255u);
+        const int jB = (int)((en >> 16) & 255u);
+        T[e] = nA[e] + (int)(en >> 24);
+        jBp[e] = jB - nA[e];
+        baseA[e] = (unsigned)__umul24(i + __umul24(L, jA[e]), a.ld);
+        baseB[e] = (unsigned)__umul24(i + __umul24(L, jB), a.ld) - (unsigned)nA[e] * strideJ;
+        src[e] = a.src + day * a.src_bstride + col;
+      }
+    }
+    int tmax = 0;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) tmax = max(tmax, T[e]);
+    if (conj_pair) {
+      double S[EL][4];
+#pragma unroll
+      for (int e = 0; e < EL; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[e][q] = 0.0;
+      for (int tb = 0; tb < tmax; tb += JB) {
+        cplx v[EL][JB];
+        int jj[EL][JB];
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int t = 0; t < JB; ++t) {
+            const int tt = tb + t;
+            v[e][t] = make_double2(0.0, 0.0);
+            const bool inA = tt < nA[e];
+            jj[e][t] = (inA ? jA[e] : jBp[e]) + tt;
+            if (tt < T[e]) v[e][t] = src[e][(inA ? baseA[e] : baseB[e]) + (unsigned)tt * strideJ];
+            else jj[e][t] = 0;
+          }
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int t = 0; t < JB; ++t) {
+            const cplx w = wj[jj[e][t]];
+            S[e][0] = fma(v[e][t].x, w.x, S[e][0]);
+            S[e][1] = fma(v[e][t].y, w.y, S[e][1]);
+            S[e][2] = fma(v[e][t].x, w.y, S[e][2]);
+            S[e][3] = fma(v[e][t].y, w.x, S[e][3]);
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < EL; ++e)
+        if (slot[e] >= 0) {
+          data[slot[e]] = cmul(make_double2(S[e][0] - S[e][1], S[e][2] + S[e][3]), stw[row[e]]);
+          data[slot[e] + gstep] = cmul(make_double2(S[e][0] + S[e][1], S[e][3] - S[e][2]), stw[L + row[e]]);
+        }
+    } else {
+      cplx acc[EL][2];
+#pragma unroll
+      for (int e = 0; e < EL; ++e) acc[e][0] = acc[e][1] = make_double2(0.0, 0.0);
+      for (int tb = 0; tb < tmax; tb += JB) {
+        cplx v[EL][JB];
+        int jj[EL][JB];
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int t = 0; t < JB; ++t) {
+            const int tt = tb + t;
+            v[e][t] = make_double2(0.0, 0.0);
+            const bool inA = tt < nA[e];
+            jj[e][t] = (inA ? jA[e] : jBp[e]) + tt;
+            if (tt < T[e]) v[e][t] = src[e][(inA ? baseA[e] : baseB[e]) + (unsigned)tt * strideJ];
+            else jj[e][t] = 0;
+          }
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int t = 0; t < JB; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[e][g] = cadd(acc[e][g], cmul(v[e][t], wj[g * a.L1 + jj[e][t]]));
+      }
+#pragma unroll
+      for (int e = 0; e < EL; ++e)
+        if (slot[e] >= 0) {
+          data[slot[e]] = cmul(acc[e][0], stw[row[e]]);
+          data[slot[e] + gstep] = cmul(acc[e][1], stw[L + row[e]]);
+        }
+    }
+  }
+}
+
 // Workgroup prologue of the fused kernels: FFT twiddle block, digit-reversal table and (direct
 // mode) the stw / wj tables of G outer indices, with ALL global loads of a round issued before
 // the first LDS store -- one memory round trip instead of one per table (they used to be six
 // of a workgroup's ~25 us).
 template <int G>
 __device__ __forceinline__ void fused_prologue(const ColFusedArgs& a, cplx* tlo, int* spos, cplx* stw, cplx* wj,
-                                               int o0, int* rng, int nd) {
+                                               int oq, unsigned* ent, int nd) {
   const FftProg& P = a.prog;
   const int n = tw_count(P), L = P.L;
-  // per-day live row ranges of the kernels (direct mode) -> LDS
-  if (a.direct && (int)threadIdx.x < 2 * nd)
-    rng[threadIdx.x] = a.live.range ? a.live.range[threadIdx.x] : ((threadIdx.x & 1) ? (1 << 30) : -(1 << 30));
+  // outer indices of the workgroup: o0 + g (G == 1: just oq), or the conjugate pair (pair_o)
+  const int og1 = G == 2 ? pair_o(oq, 1, a.L1) : oq;
+  // per (tile row, day) live terms of the kernels (direct mode) -> LDS (kt_direct_entry)
+  if (a.direct)
+    for (int t = threadIdx.x; t < a.L2 * nd; t += blockDim.x) {
+      const int i = t / nd, day = t - i * nd;
+      int lo = -(1 << 30), hi = 1 << 30;
+      if (a.live.range) { lo = a.live.range[2 * day]; hi = a.live.range[2 * day + 1]; }
+      ent[t] = kt_direct_entry(a, i, lo, hi);
+    }
   const int n_stw = a.direct ? G * a.L2 : 0, n_dir = a.direct ? G * (a.L2 + a.L1) : 0;
   const int nmax = max(max(n, L), n_dir);
   const int mask = (1 << a.tp_shift) - 1;
@@ -515,14 +666,14 @@ __device__ __forceinline__ void fused_prologue(const ColFusedArgs& a, cplx* tlo,
     if (t < L) sp = (int)P.pos[t];
     if (t < n_dir) {
       int e;
-      if (t < n_stw) {                       // stw[g * L2 + r] = w_N^{(o0 + g) r}
+      if (t < n_stw) {                       // stw[g * L2 + r] = w_N^{o_g r}
         const int g = t / a.L2, r = t - g * a.L2;
-        e = (o0 + g) * r;
+        e = (g ? og1 : oq) * r;
         dst = t;
-      } else {                               // wj[g * L1 + j] = w_L1^{j (o0 + g)}
+      } else {                               // wj[g * L1 + j] = w_L1^{j o_g}
         const int u = t - n_stw;
         const int g = u / a.L1, j = u - g * a.L1;
-        e = ((j * (o0 + g)) % a.L1) * a.L2;
+        e = ((j * (g ? og1 : oq)) % a.L1) * a.L2;
         dst = u;
       }
       hi = a.tp_hi[e >> a.tp_shift];
@@ -649,17 +800,20 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   const int ntiles = (a.ncols + W - 1) >> a.wsh;
   int tile, oq;
   if (!fused_tile_map(a, ntiles, &tile, &oq, G)) return;
-  const int o0 = oq * G;
+  // outer indices of this workgroup: G == 1: oq; G == 2: the conjugate pair (oq, L1 - oq), with
+  // (0, L1/2) as the pair oq == 0 (kt_direct_fill_pair)
+  const int oA = oq, oB = G == 2 ? pair_o(oq, 1, a.L1) : oq;
   const int c0 = tile << a.wsh;
   const int nthr = blockDim.x;
   cplx* stw = reinterpret_cast<cplx*>(spos + ((L + 3) & ~3));
   cplx* wj = stw + G * L;
-  int* rng = reinterpret_cast<int*>(wj + G * a.L1);   // [ND][2]
-  fused_prologue<G>(a, tlo, spos, stw, wj, o0, rng, ND);
+  unsigned* ent = reinterpret_cast<unsigned*>(wj + G * a.L1);   // [L2][ND]
+  fused_prologue<G>(a, tlo, spos, stw, wj, oq, ent, ND);
   const int totg = L << (a.wsh + GSH), totn = L << wshn;
   if (a.direct) {
     __syncthreads();
-    kt_direct_fill<G>(a, data, stw, wj, c0, wshn, NDSH, rng);
+    if (G == 2) kt_direct_fill_pair<ND>(a, data, stw, wj, c0, wshn, ent, oq != 0);
+    else kt_direct_fill<1>(a, data, stw, wj, c0, wshn, NDSH, nullptr);
   } else
   for (int idx0 = threadIdx.x; idx0 < totn; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL];
@@ -668,7 +822,7 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
       const int idx = idx0 + u * nthr;
       const int row = idx >> wshn, cc = idx & (WN - 1);
       const int g = cc >> wshd, day = (cc >> a.wsh) & (ND - 1), col = c0 + (cc & (W - 1));
-      const int64_t grow = (int64_t)(o0 + g) * a.L2 + row;
+      const int64_t grow = (int64_t)(g ? oB : oA) * a.L2 + row;
       v[u] = make_double2(0.0, 0.0);
       if (idx < totn && col < a.ncols && row_live(a.live, (int)grow, day))
         v[u] = a.src[day * a.src_bstride + grow * a.ld + col];
@@ -681,7 +835,7 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   }
   __syncthreads();
   lds_fft<PS_FWD, GEN>(data, tlo, thi, P, PS_MODE_COL, WN, wshn, 0);
-  // elements (k, g, c): state row o0 + g + L1 k
+  // elements (k, g, c): state row o_g + L1 k
   for (int idx0 = threadIdx.x; idx0 < totg; idx0 += nthr * PS_UNROLL) {
     cplx v[PS_UNROLL];
 #pragma unroll
@@ -689,7 +843,7 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
       const int idx = idx0 + u * nthr;
       const int k = idx >> (a.wsh + GSH), g = (idx >> a.wsh) & (G - 1), col = c0 + (idx & (W - 1));
       v[u] = make_double2(0.0, 0.0);
-      if (idx < totg && col < a.ncols) v[u] = a.state[((int64_t)(o0 + g) + (int64_t)a.L1 * k) * a.ld + col];
+      if (idx < totg && col < a.ncols) v[u] = a.state[((int64_t)(g ? oB : oA) + (int64_t)a.L1 * k) * a.ld + col];
     }
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
@@ -704,7 +858,7 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
         data[l + (day << a.wsh)] = x;
       }
       if (a.store_prod && c0 + c < a.ncols)
-        a.state[((int64_t)(o0 + g) + (int64_t)a.L1 * k) * a.ld + c0 + c] = x;
+        a.state[((int64_t)(g ? oB : oA) + (int64_t)a.L1 * k) * a.ld + c0 + c] = x;
     }
   }
   __syncthreads();
@@ -712,7 +866,7 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   for (int idx = threadIdx.x; idx < totn; idx += nthr) {
     const int row = idx >> wshn, cc = idx & (WN - 1);
     const int g = cc >> wshd, day = (cc >> a.wsh) & (ND - 1), col = c0 + (cc & (W - 1));
-    if (col < a.ncols) a.dst[day * a.dst_dstride + ((int64_t)(o0 + g) * a.L2 + row) * a.ld + col] = data[idx];
+    if (col < a.ncols) a.dst[day * a.dst_dstride + ((int64_t)(g ? oB : oA) * a.L2 + row) * a.ld + col] = data[idx];
   }
 }
 

@@ -201,15 +201,17 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
     return (sr < rlo || sr > rhi) ? -1 : sr;
   };
   const int sa = srow(ra), sb = srow(rb);
-  cplx* da = dst + (int64_t)ra * a.ld;
-  cplx* db = dst + (int64_t)rb * a.ld;
+  // row-major: element k of row r at r * ld + k; column-major (T layout): at k * tstride + r
+  const int64_t kst = a.tstride ? (int64_t)a.tstride : 1;
+  cplx* da = dst + (a.tstride ? (int64_t)ra : (int64_t)ra * a.ld);
+  cplx* db = dst + (a.tstride ? (int64_t)rb : (int64_t)rb * a.ld);
   const bool hasb = rb < a.P;
   if (sa < 0 && sb < 0) {   // uniform per row pair
     if (a.skip_zero) return;
     const cplx z = make_double2(0.0, 0.0);
     for (int k = j; k < a.H; k += S::NTHR) {
-      da[k] = z;
-      if (hasb) db[k] = z;
+      da[k * kst] = z;
+      if (hasb) db[k * kst] = z;
     }
     return;
   }
@@ -260,8 +262,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
       zm[q].y = ex[k ? L - k : 0];
       if (k <= L / 2) {
         const cplx zk = x[q];
-        da[k] = make_double2(0.5 * (zk.x + zm[q].x), 0.5 * (zk.y - zm[q].y));
-        if (hasb) db[k] = make_double2(0.5 * (zk.y + zm[q].y), -0.5 * (zk.x - zm[q].x));
+        da[k * kst] = make_double2(0.5 * (zk.x + zm[q].x), 0.5 * (zk.y - zm[q].y));
+        if (hasb) db[k * kst] = make_double2(0.5 * (zk.y + zm[q].y), -0.5 * (zk.x - zm[q].x));
       }
     }
   }

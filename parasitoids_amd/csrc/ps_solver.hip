@@ -6,6 +6,7 @@
 #include "chain_kernels.h"
 #include "fft_kernels.h"
 #include "fft_rs_kernels.h"
+#include "fft_colfull_kernels.h"
 #include "fft_rs_sizes.h"
 #include "ps_common.h"
 
@@ -142,6 +143,10 @@ struct ps_solver {
   int N = 0, M = 0, Pref = 0, Pf = 0, H = 0, ld = 0, mode = 0;
   DevPlan row_plan, col_plan1, col_plan2;
   bool split = false;
+  // full-column pipeline (fft_colfull_kernels.h): spectra are column-major and a column
+  // transform is ONE pass.  On for register-resident sizes in fast mode (and the fast-torus
+  // front of auto mode); the tiled two-sub-pass column kernels serve every other case.
+  bool tpipe = false;
   bool row_big = false;  // row plan uses the radix-18/16 butterflies (512-thread workgroups)
   int num_cu = 256;
   // flag speculation in ps_chain_run: on until this solver has seen a boundary flag
@@ -324,6 +329,11 @@ static int set_lds_attr() {
       PS_HIP(hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS)); \
       PS_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS)); \
     }                                                                                                        \
+    using Y1 = RsInvLds<16, A, B>;                                                                           \
+    if (Y1::bytes(1) > 48 * 1024) {                                                                          \
+      auto kc = k_colfull<16, A, B>;                                                                         \
+      PS_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y1::bytes(1))); \
+    }                                                                                                        \
   }
   PS_RS_SIZES(X)
 #undef X
@@ -339,6 +349,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   a.rmap = rmap; a.cmap = cmap;
   a.dst = dst; a.dst_bstride = (int64_t)s->Pf * s->ld;
   a.H = s->H; a.ld = s->ld; a.P = s->Pf;
+  a.tstride = s->tpipe ? s->Pf : 0;   // full-column pipeline: column-major output
   a.prog = s->row_plan.prog;
   a.rp = row_pairs(a.prog);
   a.pred = pred;
@@ -462,10 +473,41 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
 }
 
 // forward 2-D transform of `batch` real sources into `out`
+// one full-column pass (k_colfull): mode 0 day step (kernel -> x state -> inverse -> dst), 1 forward
+// (src -> state), 2 inverse (state -> dst), 3 product only (state *= FFT(src))
+static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, int store_prod, cplx* dst, int batch,
+                          RowLive live, const unsigned long long* pred) {
+  ColFullArgs a;
+  const int64_t spec = (int64_t)s->Pf * s->ld;   // T-layout arrays ([H][Pf]) fit the row-major allocation ([Pf][ld])
+  a.src = src; a.src_bstride = spec;
+  a.state = state; a.state_bstride = spec;
+  a.dst = dst; a.dst_bstride = spec;
+  a.ld = s->ld; a.ncols = s->H; a.mode = mode; a.store_prod = store_prod;
+  a.live = live;
+  a.pred = pred;
+  a.prog = s->row_plan.prog;
+  // see k_colfull: columns are handed out in groups of 8 x 8 XCDs
+  const int groups = (s->H + 7) / 8;
+  dim3 grid((unsigned)(((groups + 7) / 8) * 64), batch);
+  ProfScope prof(s, pred ? PS_PROF_REFFT : (mode == 1 ? PS_PROF_COL_FWD_A : PS_PROF_COL_INV_A));
+#define X(A, B)                                                                                        \
+  if (s->rs_r2 == A && s->rs_r3 == B) {                                                                \
+    auto kern = k_colfull<16, A, B>;                                                                   \
+    using C = RsCfg<A, B>;                                                                             \
+    using Y = RsInvLds<16, A, B>;                                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), Y::bytes(1), s->stream, a);                        \
+  }
+  PS_RS_SIZES(X)
+#undef X
+  PS_HIP(hipGetLastError());
+  return PS_OK;
+}
+
 static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_ld, SrcMap rmap,
                  SrcMap cmap, cplx* out, int batch, const unsigned long long* pred) {
   // zero source rows are neither written by the row pass nor read by the first column pass
   PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred, 1));
+  if (s->tpipe) return launch_colfull(s, 1, s->T1.p, out, 0, nullptr, batch, RowLive{1, rmap, nullptr}, pred);
   if (s->fwd_passes.size() == 1) {
     PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred, RowLive{1, rmap, nullptr}));
   } else {
@@ -478,6 +520,11 @@ static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_l
 // inverse 2-D transform of (A [* B]) into record `rec`; optionally stores the product
 static int inv2d(ps_solver* s, const cplx* A, const cplx* B, cplx* prod, double* rec,
                  int stat_slot, double negval, double stat_scale) {
+  if (s->tpipe) {   // only get_cursol comes here: inverse of the state itself
+    if (B || prod) return ps_fail(PS_ERR_STATE, "inv2d: product form is not used by the full-column pipeline");
+    PS_TRY(launch_colfull(s, 2, nullptr, const_cast<cplx*>(A), 0, s->T1.p, 1, RowLive{0, {0, 0, 0, 0}, nullptr}, nullptr));
+    return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
+  }
   if (s->inv_passes.size() == 1) {
     PS_TRY(launch_col<PS_INV>(s, s->inv_passes[0], A, B, prod, s->T1.p, 1, 0, nullptr));
     PS_TRY(launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale));
@@ -496,7 +543,11 @@ static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, i
                          bool direct = false) {
   const RowLive live{1, rmap, rowrange};
   s->kt_live = RowLive{0, {0, 0, 0, 0}, nullptr};
-  s->kt_direct = s->split && direct;
+  s->kt_direct = s->split && direct && !s->tpipe;
+  if (s->tpipe) {   // the day step's full-column pass reads the (column-major) row-pass output itself
+    s->kt_live = live;
+    return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr, 1, rowrange);
+  }
   if (!s->split || direct) {
     s->kt_live = live;  // the fused pass reads the row-pass output directly (one day at a time)
     return launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, out, batch, nullptr, 1, rowrange);
@@ -511,7 +562,7 @@ static void fused_direct_args(ps_solver* s, ColFusedArgs& a) {
   a.mgL2 = ps_magic((uint32_t)a.L2);
 }
 // LDS bytes of the direct-sum twiddles (stw[L2], wj[L1]) + alignment slack
-static size_t fused_direct_lds(const ColFusedArgs& a) { return a.direct ? ((size_t)a.L1 + a.L2 + 1) * sizeof(cplx) + 64 : 0; }   // + day ranges
+static size_t fused_direct_lds(const ColFusedArgs& a) { return a.direct ? ((size_t)a.L1 + a.L2 + 1) * sizeof(cplx) + 64 : 0; }   // + slack
 
 static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store_prod, cplx* dst,
                             const int* rowrange) {
@@ -581,7 +632,8 @@ static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* st
   if (const char* e = getenv("PS_MULTI_WSH")) a.wsh = atoi(e);   // tuning knob
   auto need = [&](int wsh) {
     return (((size_t)a.prog.L << (wsh + ndsh + gsh)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
-           (size_t)(a.prog.L + 4) * sizeof(int) + G * fused_direct_lds(a);
+           (size_t)(a.prog.L + 4) * sizeof(int) + G * fused_direct_lds(a) +
+           (a.direct ? (size_t)a.L2 * nd * sizeof(unsigned) : 0);   // + live-term table (kt_direct_entry)
   };
   // at least two workgroups per CU, or the single-day pass does better
   const size_t lds_cap = (size_t)kMaxLds / 2;
@@ -659,6 +711,12 @@ static int launch_col_fused_dual(ps_solver* s, const cplx* kt, const cplx* state
 // one day step: state_hat <- state_hat * K_hat (stored when store_prod), rec <- ifft2(...)
 static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, double* rec,
                     int stat_slot, double negval, double stat_scale, const int* rowrange = nullptr) {
+  if (s->tpipe) {
+    RowLive live = s->kt_live;
+    live.range = rowrange;
+    PS_TRY(launch_colfull(s, 0, kt, state, store_prod, s->T1.p, 1, live, nullptr));
+    return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
+  }
   int done = 0;
   // direct-sum kernels: the one-day instance of the multi kernel pairs outer indices (+5 %)
   if (s->kt_direct && store_prod) PS_TRY(launch_col_fused_multi(s, kt, 1, state, s->T1.p, rowrange, &done));
@@ -796,6 +854,8 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
   if (getenv("PS_NO_RS") == nullptr && !rs_lookup(s->Pf, &s->rs_r2, &s->rs_r3)) s->rs_r2 = s->rs_r3 = 0;
+  s->tpipe = mode == PS_MODE_FAST && s->rs_r2 != 0 && getenv("PS_NO_RS") == nullptr &&
+             getenv("PS_NO_RS_FWD") == nullptr && getenv("PS_NO_TPIPE") == nullptr;
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;
@@ -1043,7 +1103,8 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   // (measured: +14 % on the headline stack, whose kernels need 6-8 terms per output; break-even
   // near 8 terms at FFT size 5760; the fold-mode fused pass, with the state in the other half of
   // its tile, does not gain)
-  bool direct = s->split && s->mode != PS_MODE_FOLD && getenv("PS_NO_DIRECT") == nullptr;
+  bool direct = s->split && s->mode != PS_MODE_FOLD && getenv("PS_NO_DIRECT") == nullptr &&
+                s->L1 <= 255 && s->L2 <= 255;   // kt_direct_entry packs term indices in bytes
   if (direct) {
     static const int max_terms = getenv("PS_DIRECT_MAX_TERMS") ? atoi(getenv("PS_DIRECT_MAX_TERMS")) : 8;   // tuning knob
     for (int d = first; d < first + count && direct; ++d) {
@@ -1330,7 +1391,9 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
           int g = 0;
           // direct mode pairs outer indices (twice the tile): four days per pass there
           static const int direct_days = getenv("PS_DIRECT_DAYS") ? atoi(getenv("PS_DIRECT_DAYS")) : 4;   // tuning knob
-          const int maxd = s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days;
+          // (the full-column pipeline takes one day per pass: the state column would have to stay
+          // on chip next to the transform's registers)
+          const int maxd = s->tpipe ? 1 : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
           if (maxd > 1 && w - i >= 2) {
             const int nd = (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
             const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
@@ -1776,6 +1839,8 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
 }
 
 extern "C" int ps_solver_kernels_direct(ps_solver* s) { return s && s->kt_direct ? 1 : 0; }
+
+extern "C" int ps_solver_pipeline(ps_solver* s) { return s && s->tpipe ? 1 : 0; }
 
 extern "C" int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_fft) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");

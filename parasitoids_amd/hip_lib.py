@@ -279,6 +279,11 @@ class HipSolve():
     def sync(self):
         L.check(self._lib.ps_solver_sync(self._h))
 
+    @property
+    def full_column(self):
+        '''True when the solver runs the full-column pipeline -- measurement aid.'''
+        return bool(self._lib.ps_solver_pipeline(self._h))
+
     def auto_info(self):
         '''PS_MODE_AUTO: (first chain day of the last run_chain that ran on the folded reference
         torus, or -1 when every day was clean and ran on the fast torus; FFT size of the fold

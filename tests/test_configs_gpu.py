@@ -48,22 +48,33 @@ def _oracle_raw_chain(state, kernels, K, nd):
     return out, flags
 
 
-def test_config3_benchmarked_stack_against_oracle(hip_lib):
-    """bench.py's workload (N = 4097, K = 2049, P = 5121, fast mode on 5184): days 0-9 run as
-    speculation windows 2 + 4 + (4 of 8), i.e. through k_col_fused_multi<2> and <4> with the
-    direct-sum first column sub-pass -- against the oracle's raw fields at 1e-12."""
+@pytest.mark.parametrize('pipeline', ['full_column', 'tiled'])
+def test_config3_benchmarked_stack_against_oracle(hip_lib, monkeypatch, pipeline):
+    """bench.py's workload (N = 4097, K = 2049, P = 5121, fast mode on 5184) against the oracle's
+    raw fields at 1e-12, through both column pipelines: the full-column one bench.py runs
+    (k_colfull: one pass per column transform), and the tiled one (PS_NO_TPIPE=1), where days
+    0-9 run as speculation windows 2 + 4 + (4 of 8), i.e. through k_col_fused_multi<2> and <4>
+    with the direct-sum first column sub-pass."""
     from parasitoids_amd import synthetic
+    if pipeline == 'tiled':
+        monkeypatch.setenv('PS_NO_TPIPE', '1')
+    else:
+        monkeypatch.delenv('PS_NO_TPIPE', raising=False)
     R, K, nd = 2048, 2049, 10
     state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=30, seed=20240613)
     s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
     assert s.fft_len == 5184
+    assert s.full_column == (pipeline == 'full_column')
     s.set_kernels(kernels)                   # all 30, like the bench: same chunking and windows
     s.prof_enable(True, every=1)
     s.run_chain(0, 30, renorm=True)
     st = s.chain_stats(0, 30)
     prof = s.prof_read()
-    assert s.kernels_direct
-    assert prof['col_inv_a_x4'][1] >= 1 and prof['col_inv_a_x2'][1] >= 1     # the fused multi-day path ran
+    if pipeline == 'tiled':
+        assert s.kernels_direct
+        assert prof['col_inv_a_x4'][1] >= 1 and prof['col_inv_a_x2'][1] >= 1     # the fused multi-day path ran
+    else:
+        assert prof['col_inv_a'][1] == 30 and prof['col_inv_b'][1] == 0          # one column pass per day
     ref, flags = _oracle_raw_chain(state, kernels, K, nd)
     assert not any(flags) and not any(x.flag for x in st)
     for d in range(nd):
