@@ -24,6 +24,15 @@
 // eight XCDs round-robin), so the line is assembled in that XCD's L2 before it goes to HBM
 // (measured with scripts/microbench/scatter_write.hip: 3.4 TB/s against 1.4 TB/s for the naive
 // block order; a tiled pass writing full lines with the same row stride reaches 2.9-3.3).
+//
+// Measured and not kept (N = 4097, L = 5184; the day-step pass takes 255 us for 650 MB): two
+// columns per workgroup in lockstep, the way the row kernels pair rows -- 12 resident waves per
+// CU instead of the 5.2 a 6-wave workgroup at 162 registers gets (its second copy does not fit
+// the SIMDs' wave slots) -- 294 us: the columns then load, transform and store in the same
+// phase; touching every line of the state column (one dword) behind the kernel loads so that
+// HBM delivers it while the forward transform runs: 266 us.  The phases of a workgroup add up
+// (PMC: VALU busy 21 %, 75 % of the wave cycles waiting); what would overlap them is a second
+// INDEPENDENT workgroup per CU, i.e. <= 128 registers (a radix <= 12 four-stage plan).
 #pragma once
 #include "fft_rs_kernels.h"
 

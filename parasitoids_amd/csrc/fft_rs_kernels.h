@@ -187,9 +187,18 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
   constexpr int L = S::L;
   if (pred_skip(a.pred)) return;
   const int half = threadIdx.x / S::NTHR;
-  const int pair = ((int)gridDim.x - 1 - (int)blockIdx.x) * NP + half;   // cheap (dead) pairs first, see k_row_inv_rs
+  int unit = (int)blockIdx.x;
+  if (a.tstride) {
+    // column-major output: a 128-byte line holds 8 rows = 4 row pairs = 4 / NP workgroups, which
+    // are consecutive blocks of ONE XCD (blocks go to the XCDs round-robin) so that the line is
+    // assembled in that L2 (see k_colfull); gridDim.x is a multiple of 8 * (4 / NP)
+    constexpr int KL = NP >= 4 ? 1 : 4 / NP;
+    const int xcd = unit & 7, q = unit >> 3;
+    unit = ((q / KL) * 8 + xcd) * KL + (q % KL);
+  }
+  const int pair = ((int)gridDim.x - 1 - unit) * NP + half;   // cheap (dead) pairs first, see k_row_inv_rs
   const int ra = 2 * pair, rb = ra + 1;
-  if (ra >= a.P) return;   // ended waves do not take part in the barriers below
+  if (ra >= a.P || pair < 0) return;   // ended waves do not take part in the barriers below
   double* ex = reinterpret_cast<double*>(ps_lds_raw) + half * (Y::XW + Y::RED);
   const int j = threadIdx.x - half * S::NTHR;
   const double* src = a.src + (int64_t)blockIdx.y * a.src_bstride;

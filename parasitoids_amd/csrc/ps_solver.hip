@@ -147,6 +147,12 @@ struct ps_solver {
   // transform is ONE pass.  On for register-resident sizes in fast mode (and the fast-torus
   // front of auto mode); the tiled two-sub-pass column kernels serve every other case.
   bool tpipe = false;
+  bool tpipe_ok = false;    // the solver CAN run the full-column pipeline (register-resident size, fast mode)
+  // The state's spectrum is built lazily from its spatial record (PS_REC_STATE), in the layout
+  // of the pipeline the first consumer picks: ps_chain_run takes the tiled pipeline for compact
+  // day kernels (multi-day fused passes with direct-sum kernels) and the full-column one
+  // otherwise; the per-call API stays on the solver's default.
+  bool spec_valid = false;
   bool row_big = false;  // row plan uses the radix-18/16 butterflies (512-thread workgroups)
   int num_cu = 256;
   // flag speculation in ps_chain_run: on until this solver has seen a boundary flag
@@ -368,7 +374,9 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
       using C = RsCfg<A, B>;                                                                                 \
       constexpr int np = C::NP;                                                                              \
       auto kern = k_row_fwd_rs<16, A, B, np>;                                                                \
-      hipLaunchKernelGGL(kern, dim3((npairs + np - 1) / np, batch), dim3(C::S::NTHR * np), C::LDS, s->stream, a); \
+      int gx = (npairs + np - 1) / np;                                                                       \
+      if (a.tstride) { const int m = 8 * (np >= 4 ? 1 : 4 / np); gx = (gx + m - 1) / m * m; }               \
+      hipLaunchKernelGGL(kern, dim3(gx, batch), dim3(C::S::NTHR * np), C::LDS, s->stream, a);                 \
     }
     PS_RS_SIZES(X)
 #undef X
@@ -854,8 +862,9 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
   if (getenv("PS_NO_RS") == nullptr && !rs_lookup(s->Pf, &s->rs_r2, &s->rs_r3)) s->rs_r2 = s->rs_r3 = 0;
-  s->tpipe = mode == PS_MODE_FAST && s->rs_r2 != 0 && getenv("PS_NO_RS") == nullptr &&
-             getenv("PS_NO_RS_FWD") == nullptr && getenv("PS_NO_TPIPE") == nullptr;
+  s->tpipe_ok = mode == PS_MODE_FAST && s->rs_r2 != 0 && getenv("PS_NO_RS") == nullptr &&
+                getenv("PS_NO_RS_FWD") == nullptr && getenv("PS_NO_TPIPE") == nullptr;
+  s->tpipe = s->tpipe_ok;
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;
@@ -1051,9 +1060,30 @@ int ps_solver_set_state_device_coo(ps_solver* s, const int* row, const int* col,
     s->have_state = true;
     return PS_OK;
   }
-  PS_TRY(fwd2d(s, rec, 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), s->Ahat.p, 1, nullptr));
+  s->spec_valid = false;   // transformed by the first consumer (ensure_spectrum)
   s->have_state = true;
   return PS_OK;
+}
+
+// Ahat <- transform of the spatial state record, in the layout of the current pipeline
+static int ensure_spectrum(ps_solver* s) {
+  if (s->spec_valid || s->mode == PS_MODE_FOLD) return PS_OK;
+  if (s->recs[PS_REC_STATE].empty() || !s->recs[PS_REC_STATE][0]) return ps_fail(PS_ERR_STATE, "no state record");
+  PS_TRY(ensure_temps(s, 1));
+  PS_TRY(fwd2d(s, s->recs[PS_REC_STATE][0], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), s->Ahat.p, 1, nullptr));
+  s->spec_valid = true;
+  return PS_OK;
+}
+
+// switch between the tiled and the full-column pipeline; only possible while the state's
+// spectrum has not been built (or can be rebuilt from its record)
+static void set_pipeline(ps_solver* s, bool tpipe) {
+  if (!s->tpipe_ok) tpipe = false;
+  if (s->tpipe == tpipe) return;
+  s->tpipe = tpipe;
+  s->bhat_first = -1;      // kernel transforms and cached filter spectra are layout-specific
+  s->bhat_count = 0;
+  s->filt_keys.clear();
 }
 
 extern "C" int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const int32_t* col,
@@ -1063,6 +1093,23 @@ extern "C" int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const i
   PS_TRY(check_coo(row, col, nnz, s->N, "state"));
   PS_TRY(upload_coo(s, row, col, val, nnz));
   return ps_solver_set_state_device_coo(s, s->orow.p, s->ocol.p, s->oval.p, nnz, 0);
+}
+
+// compact day kernels (few live rows per residue class of the column split) can take the
+// direct-sum first column sub-pass of the tiled pipeline (kt_direct_fill)
+static bool direct_possible(const ps_solver* s) {
+  return s->split && s->mode != PS_MODE_FOLD && getenv("PS_NO_DIRECT") == nullptr &&
+         s->L1 <= 255 && s->L2 <= 255;   // kt_direct_entry packs term indices in bytes
+}
+static bool day_is_compact(const ps_solver* s, int d) {
+  static const int max_terms = getenv("PS_DIRECT_MAX_TERMS") ? atoi(getenv("PS_DIRECT_MAX_TERMS")) : 8;   // tuning knob
+  const int M = s->Kmax / 2;
+  const int lo = s->hkrange[2 * d], hi = s->hkrange[2 * d + 1];
+  if (lo > hi) return true;
+  // live rows split at the kernel centre M into the two wrapped intervals
+  const int below = std::max(0, std::min(hi, M - 1) - lo + 1), above = std::max(0, hi - std::max(lo, M) + 1);
+  const int terms = (below + s->L2 - 1) / s->L2 + (above + s->L2 - 1) / s->L2;
+  return terms <= max_terms;
 }
 
 // transform `count` kernels starting at day `first` into Bhat[0..count)
@@ -1103,19 +1150,8 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   // (measured: +14 % on the headline stack, whose kernels need 6-8 terms per output; break-even
   // near 8 terms at FFT size 5760; the fold-mode fused pass, with the state in the other half of
   // its tile, does not gain)
-  bool direct = s->split && s->mode != PS_MODE_FOLD && getenv("PS_NO_DIRECT") == nullptr &&
-                s->L1 <= 255 && s->L2 <= 255;   // kt_direct_entry packs term indices in bytes
-  if (direct) {
-    static const int max_terms = getenv("PS_DIRECT_MAX_TERMS") ? atoi(getenv("PS_DIRECT_MAX_TERMS")) : 8;   // tuning knob
-    for (int d = first; d < first + count && direct; ++d) {
-      const int lo = s->hkrange[2 * d], hi = s->hkrange[2 * d + 1];
-      if (lo > hi) continue;
-      // live rows split at the kernel centre M into the two wrapped intervals
-      const int below = std::max(0, std::min(hi, M - 1) - lo + 1), above = std::max(0, hi - std::max(lo, M) + 1);
-      const int terms = (below + s->L2 - 1) / s->L2 + (above + s->L2 - 1) / s->L2;
-      if (terms > max_terms) direct = false;
-    }
-  }
+  bool direct = direct_possible(s);
+  for (int d = first; d < first + count && direct; ++d) direct = day_is_compact(s, d);
   PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count,
                        s->krange.p + 2 * first, direct));
   s->bhat_first = first;
@@ -1353,6 +1389,19 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       s->hflags_n = first + count;
     }
   }
+  // Pipeline of this run, chosen while the state's spectrum is still to be built: compact day
+  // kernels on a split column transform do best in the tiled pipeline (multi-day fused passes
+  // with direct-sum kernels: 2650 against 2420 grid-days/s on the synthetic N = 4097 stack);
+  // everything else -- broad prob_mass kernels, flagged days -- in the full-column pipeline
+  // (Carnarvon R = 2048: 1040 -> 1440 grid-days/s).  Single-pass column sizes keep the tiled one.
+  if (s->tpipe_ok && !s->spec_valid) {
+    bool compact = direct_possible(s);
+    for (int d = first; d < first + count && compact; ++d) compact = day_is_compact(s, d);
+    bool want = s->split && !compact;
+    if (const char* e = getenv("PS_TPIPE")) want = atoi(e) != 0;   // A/B knob
+    set_pipeline(s, want);
+  }
+  PS_TRY(ensure_spectrum(s));
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
     PS_TRY(transform_kernels(s, c0, cn));
@@ -1474,6 +1523,7 @@ extern "C" int ps_solver_fftconv2_coo(ps_solver* s, const int32_t* row, const in
   if (kshape > s->Pf) return ps_fail(PS_ERR_BAD_SHAPE, "kernel shape %d larger than the pad %d", kshape, s->Pf);
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(check_coo(row, col, nnz, kshape, "kernel"));
+  PS_TRY(ensure_spectrum(s));
   PS_TRY(upload_coo(s, row, col, val, nnz));
   const int K = kshape, M = K / 2;
   const size_t spec = (size_t)s->Pf * s->ld;
@@ -1497,6 +1547,7 @@ extern "C" int ps_solver_get_cursol(ps_solver* s, double negval, double stat_sca
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(ensure_record(s, PS_REC_CHAIN, 0));
   PS_TRY(ensure_temps(s, 1));
+  PS_TRY(ensure_spectrum(s));
   PS_HIP(hipMemsetAsync(s->padmax.p, 0, sizeof(unsigned long long), s->stream));
   double* rec = s->recs[PS_REC_CHAIN][0];
   PS_TRY(inv2d(s, s->Ahat.p, nullptr, nullptr, rec, 0, negval, stat_scale));
@@ -1522,6 +1573,7 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
   PS_TRY(s->kdense.ensure((size_t)K * K));
   PS_TRY(ensure_temps(s, 1));
   PS_TRY(ensure_stats(s, std::max(4, nfilt)));
+  PS_TRY(ensure_spectrum(s));
   s->bhat_first = -1;
   // the back-solve statistics live in their own slots after the call; reuse slots [0,nfilt)
   PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
@@ -1770,6 +1822,11 @@ extern "C" int ps_solver_get_spectrum(ps_solver* s, double* out) {
   if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "get_spectrum: PS_MODE_FOLD offers the chain API only");
   if (!s->have_state) return ps_fail(PS_ERR_STATE, "get_spectrum before set_state");
   PS_HIP(hipSetDevice(s->device));
+  if (s->tpipe) {   // the P x P spectrum interface is row-major: tiled pipeline
+    if (s->spec_valid) return ps_fail(PS_ERR_UNSUPPORTED, "get_spectrum: the state is held column-major (full-column pipeline)");
+    set_pipeline(s, false);
+  }
+  PS_TRY(ensure_spectrum(s));
   const size_t full = (size_t)s->Pf * s->Pf;
   DevBuf<cplx> tmp;
   PS_TRY(tmp.ensure(full));
@@ -1786,6 +1843,7 @@ extern "C" int ps_solver_set_spectrum(ps_solver* s, const double* in) {
   if (!s || !in) return ps_fail(PS_ERR_BAD_ARG, "set_spectrum: bad arguments");
   if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "set_spectrum: PS_MODE_FOLD offers the chain API only");
   PS_HIP(hipSetDevice(s->device));
+  set_pipeline(s, false);   // row-major half spectrum
   const size_t full = (size_t)s->Pf * s->Pf;
   DevBuf<cplx> tmp;
   PS_TRY(tmp.ensure(full));
@@ -1798,6 +1856,7 @@ extern "C" int ps_solver_set_spectrum(ps_solver* s, const double* in) {
   tmp.release();
   if (e != hipSuccess) return ps_fail(PS_ERR_HIP, "set_spectrum: %s", hipGetErrorString(e));
   s->have_state = true;
+  s->spec_valid = true;
   return PS_OK;
 }
 

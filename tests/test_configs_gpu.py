@@ -51,23 +51,22 @@ def _oracle_raw_chain(state, kernels, K, nd):
 @pytest.mark.parametrize('pipeline', ['full_column', 'tiled'])
 def test_config3_benchmarked_stack_against_oracle(hip_lib, monkeypatch, pipeline):
     """bench.py's workload (N = 4097, K = 2049, P = 5121, fast mode on 5184) against the oracle's
-    raw fields at 1e-12, through both column pipelines: the full-column one bench.py runs
-    (k_colfull: one pass per column transform), and the tiled one (PS_NO_TPIPE=1), where days
+    raw fields at 1e-12, through both column pipelines: the full-column one
+    (k_colfull: one pass per column transform, what real-wind kernels get), and the tiled one
+    (what ps_chain_run picks for this stack's compact kernels), where days
     0-9 run as speculation windows 2 + 4 + (4 of 8), i.e. through k_col_fused_multi<2> and <4>
     with the direct-sum first column sub-pass."""
     from parasitoids_amd import synthetic
-    if pipeline == 'tiled':
-        monkeypatch.setenv('PS_NO_TPIPE', '1')
-    else:
-        monkeypatch.delenv('PS_NO_TPIPE', raising=False)
+    # ps_chain_run picks the tiled pipeline for these compact kernels by itself; PS_TPIPE forces either
+    monkeypatch.setenv('PS_TPIPE', '1' if pipeline == 'full_column' else '0')
     R, K, nd = 2048, 2049, 10
     state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=30, seed=20240613)
     s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
     assert s.fft_len == 5184
-    assert s.full_column == (pipeline == 'full_column')
     s.set_kernels(kernels)                   # all 30, like the bench: same chunking and windows
     s.prof_enable(True, every=1)
     s.run_chain(0, 30, renorm=True)
+    assert s.full_column == (pipeline == 'full_column')
     st = s.chain_stats(0, 30)
     prof = s.prof_read()
     if pipeline == 'tiled':

@@ -350,3 +350,54 @@ def test_multi_day_fused_pass_is_bit_identical(hip_lib, monkeypatch, R, K, mode)
         s.close()
     for a, b in zip(out['1'], out['8']):
         assert np.array_equal(a, b)
+
+
+def test_full_column_pipeline_matches_tiled_pipeline(hip_lib, monkeypatch):
+    """The full-column pipeline (k_colfull, column-major spectra; what ps_chain_run picks for
+    broad day kernels on register-resident FFT sizes in fast mode) against the tiled pipeline on
+    the same fast torus: chains with boundary flags (re-FFT through the full-column forward
+    pass), the per-call API (fftconv2 / get_cursol / back_solve incl. the cached filter spectra),
+    at two register-resident sizes.  Same arithmetic up to round-off: 1e-14."""
+    from parasitoids_amd import _lib as L
+    rng = np.random.default_rng(5)
+    for R, K in ((640, 801), (1000, 1201)):
+        N = 2 * R + 1
+
+        def kern(seed, n=3000):
+            r = np.random.default_rng(seed)
+            k = sparse.coo_matrix((r.random(n) + 0.05, (r.integers(0, K, n), r.integers(K // 2 - 60, K // 2 + 61, n))),
+                                  shape=(K, K))
+            k.sum_duplicates()
+            return (k / k.sum()).tocoo()
+
+        kernels = [kern(i) for i in range(6)]
+        # mass next to the upper domain edge: the broad kernels push it over -> flags
+        st = sparse.coo_matrix((rng.random(80) + 0.1, (rng.integers(2, 40, 80), rng.integers(R - 30, R + 30, 80))),
+                               shape=(N, N))
+        st = (st / st.sum()).tocoo()
+        out = {}
+        for tag in ('full_column', 'tiled'):
+            monkeypatch.setenv('PS_TPIPE', '1' if tag == 'full_column' else '0')
+            s = hip_lib.HipSolve(st, [K, K], mode='fast', chain_only=True)
+            s.set_kernels(kernels)
+            s.run_chain(renorm=True)
+            stats = s.chain_stats(0, len(kernels))
+            assert s.full_column == (tag == 'full_column')
+            fields = [s.dense(0, d) for d in range(len(kernels))]
+            flags = [bool(x.flag) for x in stats]
+            # per-call API on a fresh state: two day steps, then the back-solve of two filters, twice
+            # (the second call takes the filters' spectra from the cache)
+            s.set_state(st)
+            per = []
+            for d in range(2):
+                s.fftconv2(kernels[d])
+                per.append(s.get_cursol([N, N]).toarray())
+            filt = [sparse.coo_matrix(np.pad(kernels[d].toarray(), (N - K) // 2)) for d in (2, 3)]
+            for rep in range(2):
+                per += [m.toarray() for m in s.back_solve(filt, [N, N])]
+            out[tag] = (fields, flags, per, s.fft_len)
+            s.close()
+        assert out['full_column'][3] == out['tiled'][3] and out['tiled'][3] > 1200
+        assert out['full_column'][1] == out['tiled'][1] and any(out['tiled'][1])
+        for a, b in zip(out['full_column'][0] + out['full_column'][2], out['tiled'][0] + out['tiled'][2]):
+            assert np.abs(a - b).max() <= 1e-14 * max(1.0, np.abs(b).max())
