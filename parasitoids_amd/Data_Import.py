@@ -7,9 +7,14 @@ Input files (`data_dir`, default parasitoids_amd/data): the reference's plain-te
 `<site>fields.txt`, `<site>releasegrid.txt`, and CSV exports of its xlsx sheets made by
 tests/golden/make_locinfo_fixtures.py (same cell contents, dates as ISO strings).
 
-Only the Kalbar data set is wired up, like in the reference (Data_Import.py:453,:525,:586,:639).
-No golden vectors exist for this loader (the reference's cannot run here): tests check it
-against direct reductions of the CSV files -- "parity unpinned", see DESIGN.md.
+Only the Kalbar data set is wired up, like in the reference: every `location` branch of its
+LocInfo other than 'kalbar' raises NotImplementedError (Data_Import.py:440,:491,:519,:561,:584,
+:634), and `data/` holds field geometry and observation sheets for Kalbar only (Carnarvon has
+wind and `carnarvonearlemergence.txt`, read by ParasitoidModel.emergence_data).
+The reference's loader cannot run here, so no golden output exists; what the reference itself
+holds for it are the assertions of its `test_LocInfo` / `test_model_emergence` /
+`test_model_sampling` (tests/test_Bayes.py:39-230), which tests/test_locinfo_reference.py
+replays against this class, next to direct reductions of the CSV files.
 """
 import math
 import os
@@ -42,13 +47,20 @@ def _data_lines(filename):
 
 
 def read_field_polygons(filename, center):
-    '''dict id -> [(x, y), ...] polygon vertices in metres (Data_Import.py:262-337): an
-    identifier line, then one `lat,long` vertex per line, fields separated by blank lines.'''
+    '''dict id -> matplotlib Path of the field boundary, vertices in metres from the release
+    point (Data_Import.py:262-337, `LocInfo.get_fields`): an identifier line, then one
+    `lat,long` vertex per line, fields separated by blank lines.'''
+    from matplotlib.path import Path
     polys, verts, fid = {}, [], None
+
+    def close(verts):
+        codes = [Path.MOVETO] + [Path.LINETO] * (len(verts) - 1) + [Path.CLOSEPOLY]
+        return Path(list(verts) + [(0., 0.)], codes)
+
     for line in _data_lines(filename):
         if line == '':
             if verts:
-                polys[fid] = verts
+                polys[fid] = close(verts)
             verts, fid = [], None
         elif fid is None:
             fid = line
@@ -56,22 +68,19 @@ def read_field_polygons(filename, center):
             lat, lon = line.split(',')[:2]
             verts.append(latlong_tocoord(center, float(lat), float(lon)))
     if verts:
-        polys[fid] = verts
+        polys[fid] = close(verts)
     return polys
 
 
 def field_cells(polys, domain_info):
     '''dict id -> int array [(row, col), ...] of the cells whose centre lies inside the field
     polygon (Data_Import.py:343-368; same point-in-polygon routine, matplotlib Path).'''
-    from matplotlib.path import Path
     R = int(domain_info[1])
     res = domain_info[0] / domain_info[1]
     colmesh, rowmesh = np.meshgrid(res * np.arange(-R, R + 1), res * np.arange(R, -R - 1, -1))
     centers = np.array([colmesh.flatten(), rowmesh.flatten()]).T
     out = {}
-    for fid, verts in polys.items():
-        codes = [Path.MOVETO] + [Path.LINETO] * (len(verts) - 1) + [Path.CLOSEPOLY]
-        path = Path(list(verts) + [(0., 0.)], codes)
+    for fid, path in polys.items():
         out[fid] = np.argwhere(path.contains_points(centers).reshape(2 * R + 1, 2 * R + 1))
     return out
 
@@ -108,7 +117,7 @@ class LocInfo(object):
         ##### sentinel fields (Data_Import.py:62-72)
         self.field_polys = read_field_polygons(os.path.join(d, location + 'fields.txt'), release_latlong)
         self.field_cells = field_cells(self.field_polys, domain_info)
-        self.field_sizes = {k: max(v.shape) for k, v in self.field_cells.items()}
+        self.field_sizes = {k: int(max(v.shape)) for k, v in self.field_cells.items()}
 
         ##### release-field grid (Data_Import.py:74-113)
         self.grid_data = read_release_grid(os.path.join(d, location + 'releasegrid.txt'))

@@ -146,7 +146,7 @@ def test_locinfo_loader_kalbar():
         assert c.ndim == 2 and c.shape[1] == 2 and c.min() >= 0 and c.max() < N
         assert li.field_sizes[k] == len(c) > 10
         # cell centres of a field lie inside the bounding box of its polygon
-        xy = np.array(li.field_polys[k])
+        xy = np.asarray(li.field_polys[k].vertices[:-1])      # Path: last vertex closes the polygon
         x = (c[:, 1] - R) * 25.0
         y = (R - c[:, 0]) * 25.0
         assert x.min() >= xy[:, 0].min() - 1e-9 and x.max() <= xy[:, 0].max() + 1e-9
