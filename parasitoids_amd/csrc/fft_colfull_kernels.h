@@ -44,13 +44,19 @@ struct ColFullArgs {
   cplx* dst;             // row-major [L][ld] (modes 0, 2)
   int64_t dst_bstride;
   int ld, ncols, mode, store_prod;
-  RowLive live;          // rows of src that were never written (known zero)
+  int nd;                // mode 0: consecutive days in this pass
+  int64_t src_dstride, dst_dstride;   // per day
+  RowLive live;          // rows of src that were never written (known zero); range advances 2 ints per day
   const unsigned long long* pred;
   FftProg prog;          // the length-L row plan (its two-level twiddle table)
 };
 
+// Single day step (mode 0 with nd == 1), the state column straight from HBM: the form the
+// compiler turns into 162 registers and no scratch (255 us per day at L = 5184).  The templated
+// kernel below serves the other modes (114-128 registers) and the chained groups of days; its
+// one-day instance costs 246-256 registers and is 15-45 % slower than this one.
 template <int R1, int R2, int R3>
-__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs a) {
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullArgs a) {
   using S = Rs<R1, R2, R3>;
   constexpr int L = S::L;
   if (pred_skip(a.pred)) return;
@@ -128,5 +134,145 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
     cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + c;
 #pragma unroll
     for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * a.ld] = x[q];
+  }
+}
+
+// A 6-wave workgroup at ~160 registers is alone on its CU anyway (see above), so the 160 KB of
+// LDS are its own: with CHAIN the state column is parked in LDS next to the exchange buffer
+// (every thread keeps the elements k = j + q T3 it multiplies -- private slots, no barrier)
+// from the first load to the last store.  That puts the column's HBM round trip behind the first
+// forward transform and lets ONE pass take `nd` consecutive un-flagged days -- A_{d+1} = A_d K_d
+// chained on chip, the same products in the same order as nd single-day passes -- with the
+// state read and written once instead of nd times (mode 0; kernels at src + day * src_dstride,
+// outputs at dst + day * dst_dstride, live ranges at live.range + 2 * day).  Sizes whose column
+// does not fit next to the exchange buffer (L > 6400) run CHAIN = false, one day per pass.
+// (Holding the column in registers instead: 256 VGPRs and 1.2 KB of scratch per thread, 3x slower.)
+template <int R1, int R2, int R3, bool CHAIN, int MODE>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs a) {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  constexpr int L = S::L;
+  if (pred_skip(a.pred)) return;
+  // block -> column: blocks b, b+8, ..., b+56 (one XCD, dispatched back to back) own the eight
+  // columns of one 128-byte line of the row-major output
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
+  if (c >= a.ncols) return;   // whole workgroup: no barrier is pending
+  double* ex = reinterpret_cast<double*>(ps_lds_raw);
+  cplx* sst = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);   // CHAIN: the state column, [L]
+  const int j = threadIdx.x;
+  const FftProg& P = a.prog;
+  const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
+  const cplx w3 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
+  cplx* st = a.state + (int64_t)blockIdx.y * a.state_bstride + (int64_t)c * L;
+  if constexpr (MODE == 2) {           // inverse of the state itself
+    cplx x[S::RMAX];
+    if (j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) x[q] = st[j + q * S::T1];
+      bfly<R1, PS_INV>(x);
+    }
+    rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
+    if (j < S::T3) {
+      cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + c;
+#pragma unroll
+      for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * a.ld] = x[q];
+    }
+  } else if constexpr (MODE == 1) {    // forward: row-pass output column -> state column
+    cplx x[S::RMAX];
+    const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)c * L;
+    if (j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) {
+        const int n = j + q * S::T1;
+        x[q] = make_double2(0.0, 0.0);
+        if (row_live(a.live, n, (int)blockIdx.y)) x[q] = sc[n];
+      }
+      bfly<R1, PS_FWD>(x);
+    }
+    rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);
+    if (j < S::T3) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) st[j + q * S::T3] = x[q];
+    }
+  } else {                             // MODE 0: day steps; MODE 3: product only
+    constexpr bool chain = CHAIN;
+    if (chain && j < S::T3) {   // natural order k = j + q T3: the forward transform's output order
+#pragma unroll
+      for (int q = 0; q < R3; ++q) sst[j + q * S::T3] = st[j + q * S::T3];
+    }
+    const int nd = (CHAIN && MODE == 0) ? a.nd : 1;
+    for (int day = 0; day < nd; ++day) {
+      cplx x[S::RMAX];
+      // opaque copy of the thread index: keeps the compiler from hoisting the body's ~100
+      // loop-invariant addresses out of the day loop (256 registers and scratch otherwise)
+      int jv = threadIdx.x;
+      asm volatile("" : "+v"(jv));
+      const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)day * a.src_dstride + (int64_t)c * L;
+      if (jv < S::T1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+          const int n = jv + q * S::T1;
+          x[q] = make_double2(0.0, 0.0);
+          if (row_live(a.live, n, (int)blockIdx.y + day)) x[q] = sc[n];
+        }
+        bfly<R1, PS_FWD>(x);
+      }
+      rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, jv, w2, w3);   // thread jv < T3: X[jv + q T3]
+      if (jv < S::T3) {
+        if (chain) {
+#pragma unroll
+          for (int q = 0; q < R3; ++q) {
+            x[q] = cmul(sst[jv + q * S::T3], x[q]);
+            sst[jv + q * S::T3] = x[q];
+          }
+        } else {
+          cplx sv[R3];
+#pragma unroll
+          for (int q = 0; q < R3; ++q) sv[q] = st[jv + q * S::T3];
+#pragma unroll
+          for (int q = 0; q < R3; ++q) {
+            x[q] = cmul(sv[q], x[q]);
+            if (a.store_prod) st[jv + q * S::T3] = x[q];
+          }
+        }
+      }
+      if constexpr (MODE == 0) {
+        // natural order (jv + q T3) -> first-stage input order (jv + q T1), real parts then imaginary
+        __syncthreads();
+        if (jv < S::T3) {
+#pragma unroll
+          for (int q = 0; q < R3; ++q) ex[jv + q * S::T3] = x[q].x;
+        }
+        __syncthreads();
+        if (jv < S::T1) {
+#pragma unroll
+          for (int q = 0; q < R1; ++q) x[q].x = ex[jv + q * S::T1];
+        }
+        __syncthreads();
+        if (jv < S::T3) {
+#pragma unroll
+          for (int q = 0; q < R3; ++q) ex[jv + q * S::T3] = x[q].y;
+        }
+        __syncthreads();
+        if (jv < S::T1) {
+#pragma unroll
+          for (int q = 0; q < R1; ++q) x[q].y = ex[jv + q * S::T1];
+        }
+        __syncthreads();
+        if (jv < S::T1) bfly<R1, PS_INV>(x);
+        rs_tail<S, R1, R2, R3, PS_INV>(x, ex, jv, w2, w3);     // thread jv < T3: spatial rows jv + q T3
+        if (jv < S::T3) {
+          cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)day * a.dst_dstride + c;
+#pragma unroll
+          for (int q = 0; q < R3; ++q) d[(int64_t)(jv + q * S::T3) * a.ld] = x[q];
+        }
+        if (day + 1 < nd) __syncthreads();   // the exchange buffer is reused by the next day's transform
+      }
+    }
+    if (chain && a.store_prod && j < S::T3) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) st[j + q * S::T3] = sst[j + q * S::T3];
+    }
   }
 }

@@ -292,6 +292,11 @@ struct RsCfg {
   // row pairs per workgroup: up to 12 waves (3 per SIMD at the ~165 registers of a radix-18 stage)
   static constexpr int NP = 12 / W < 1 ? 1 : (12 / W > 4 ? 4 : 12 / W);
   static constexpr size_t LDS = RsInvLds<16, R2, R3>::bytes(NP);
+  // full-column pass: one column per workgroup; the state column is parked in LDS next to the
+  // exchange buffer when both fit (k_colfull CHAIN)
+  static constexpr size_t LDSC1 = RsInvLds<16, R2, R3>::bytes(1);
+  static constexpr bool CHAIN = LDSC1 + (size_t)S::L * sizeof(cplx) <= (size_t)160 * 1024;
+  static constexpr size_t LDSC = CHAIN ? LDSC1 + (size_t)S::L * sizeof(cplx) : LDSC1;
 };
 static bool rs_lookup(int L, int* r2, int* r3) {
 #define X(A, B) if (L == 16 * A * B) { *r2 = A; *r3 = B; return true; }
@@ -335,10 +340,12 @@ static int set_lds_attr() {
       PS_HIP(hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS)); \
       PS_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS)); \
     }                                                                                                        \
-    using Y1 = RsInvLds<16, A, B>;                                                                           \
-    if (Y1::bytes(1) > 48 * 1024) {                                                                          \
-      auto kc = k_colfull<16, A, B>;                                                                         \
-      PS_HIP(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Y1::bytes(1))); \
+    if (C::LDSC > 48 * 1024) {                                                                               \
+      const void* kc[5] = {(const void*)k_colfull_day<16, A, B>, (const void*)k_colfull<16, A, B, false, 1>, \
+                           (const void*)k_colfull<16, A, B, false, 2>, (const void*)k_colfull<16, A, B, false, 3>, \
+                           (const void*)k_colfull<16, A, B, C::CHAIN, 0>};                                   \
+      for (const void* kk : kc)                                                                              \
+        PS_HIP(hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDSC));           \
     }                                                                                                        \
   }
   PS_RS_SIZES(X)
@@ -484,31 +491,51 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
 // one full-column pass (k_colfull): mode 0 day step (kernel -> x state -> inverse -> dst), 1 forward
 // (src -> state), 2 inverse (state -> dst), 3 product only (state *= FFT(src))
 static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, int store_prod, cplx* dst, int batch,
-                          RowLive live, const unsigned long long* pred) {
+                          RowLive live, const unsigned long long* pred, int nd = 1) {
   ColFullArgs a;
   const int64_t spec = (int64_t)s->Pf * s->ld;   // T-layout arrays ([H][Pf]) fit the row-major allocation ([Pf][ld])
   a.src = src; a.src_bstride = spec;
   a.state = state; a.state_bstride = spec;
   a.dst = dst; a.dst_bstride = spec;
   a.ld = s->ld; a.ncols = s->H; a.mode = mode; a.store_prod = store_prod;
+  a.nd = nd; a.src_dstride = spec; a.dst_dstride = spec;
   a.live = live;
   a.pred = pred;
   a.prog = s->row_plan.prog;
   // see k_colfull: columns are handed out in groups of 8 x 8 XCDs
   const int groups = (s->H + 7) / 8;
   dim3 grid((unsigned)(((groups + 7) / 8) * 64), batch);
-  ProfScope prof(s, pred ? PS_PROF_REFFT : (mode == 1 ? PS_PROF_COL_FWD_A : PS_PROF_COL_INV_A));
+  ProfScope prof(s, pred ? PS_PROF_REFFT
+                          : (mode == 1 ? PS_PROF_COL_FWD_A
+                                       : (nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4
+                                          : nd == 8 ? PS_PROF_COL_INV_A8 : PS_PROF_COL_INV_A)));
 #define X(A, B)                                                                                        \
   if (s->rs_r2 == A && s->rs_r3 == B) {                                                                \
-    auto kern = k_colfull<16, A, B>;                                                                   \
     using C = RsCfg<A, B>;                                                                             \
-    using Y = RsInvLds<16, A, B>;                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), Y::bytes(1), s->stream, a);                        \
+    if (nd > 1 && !C::CHAIN) return ps_fail(PS_ERR_UNSUPPORTED, "full-column pass: no room to chain days"); \
+    /* single passes take the state straight from HBM (162 registers, 255 us per day at 5184); only a  \
+       group of chained days parks it in LDS (246 registers: 294 us for one day, 218 per day for eight) */ \
+    auto k0 = k_colfull_day<16, A, B>;                                                                 \
+    auto k1 = k_colfull<16, A, B, false, 1>;                                                           \
+    auto k2 = k_colfull<16, A, B, false, 2>;                                                           \
+    auto k3 = k_colfull<16, A, B, false, 3>;                                                           \
+    auto kc = k_colfull<16, A, B, C::CHAIN, 0>;                                                        \
+    const bool chained = mode == 0 && nd > 1;                                                          \
+    auto kern = chained ? kc : (mode == 0 ? k0 : mode == 1 ? k1 : mode == 2 ? k2 : k3);                \
+    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), chained ? C::LDSC : C::LDSC1, s->stream, a);       \
   }
   PS_RS_SIZES(X)
 #undef X
   PS_HIP(hipGetLastError());
   return PS_OK;
+}
+
+// can the full-column pass of this size chain days (state column parked in LDS)?
+static bool colfull_chains(const ps_solver* s) {
+#define X(A, B) if (s->rs_r2 == A && s->rs_r3 == B) return RsCfg<A, B>::CHAIN;
+  PS_RS_SIZES(X)
+#undef X
+  return false;
 }
 
 static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_ld, SrcMap rmap,
@@ -739,6 +766,17 @@ static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, dou
                           double negval, double stat_scale, const int* rowrange, int* done) {
   const size_t spec = (size_t)s->Pf * s->ld;
   PS_TRY(s->T1.ensure(spec * nd));
+  if (s->tpipe) {   // nd days chained on chip by the full-column pass, then the row passes
+    *done = 0;
+    if (!colfull_chains(s)) return PS_OK;
+    RowLive live = s->kt_live;
+    live.range = rowrange;
+    PS_TRY(launch_colfull(s, 0, kt, state, 1, s->T1.p, 1, live, nullptr, nd));
+    for (int i = 0; i < nd; ++i)
+      PS_TRY(launch_row_inv(s, s->T1.p + i * spec, recs[i], d0 + i, 1, negval, stat_scale));
+    *done = 1;
+    return PS_OK;
+  }
   PS_TRY(launch_col_fused_multi(s, kt, nd, state, s->T1.p, rowrange, done));
   if (!*done) return PS_OK;
   for (int i = 0; i < nd; ++i) {
@@ -1440,9 +1478,10 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
           int g = 0;
           // direct mode pairs outer indices (twice the tile): four days per pass there
           static const int direct_days = getenv("PS_DIRECT_DAYS") ? atoi(getenv("PS_DIRECT_DAYS")) : 4;   // tuning knob
-          // (the full-column pipeline takes one day per pass: the state column would have to stay
-          // on chip next to the transform's registers)
-          const int maxd = s->tpipe ? 1 : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
+          // (the full-column pipeline chains the days with the state column in registers)
+          static const int tpipe_days = getenv("PS_TPIPE_DAYS") ? atoi(getenv("PS_TPIPE_DAYS")) : 8;   // tuning knob
+          const int maxd = s->tpipe ? std::min(s->fused_days, tpipe_days)
+                                    : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
           if (maxd > 1 && w - i >= 2) {
             const int nd = (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
             const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
