@@ -1,30 +1,39 @@
 #!/bin/bash
-# Collect the judged artefacts of one round on the GPU box: bench line, rocprofv3 kernel
-# stats of the same command, HBM traffic counters (two passes), Bayes bench, parity report,
-# HBM calibration.  usage: scripts/collect_profiles.sh TAG   (from the repo root; writes
-# gpurun_out/TAG_* -- copy into profiles/ afterwards)
+# rocprofv3 evidence for one round, run on the GPU box from the repo root:
+#   kernel-trace statistics of the default bench.py command and of the real-wind chains
+#   (bench_extras.py real_wind), and HBM traffic per kernel from two PMC passes each
+#   (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; counters are collected in their
+#   own runs with --kernel-trace only, as the pool requires).
+# usage: scripts/collect_profiles.sh TAG      -> gpurun_out/prof_TAG/
 set -e
-tag=$1
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out
+out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
-python3 "$root/bench.py" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
-python3 "$root/bench_bayes.py" > "$out/${tag}_bench_bayes.json" 2>> "$out/${tag}_bench.err"
-python3 "$root/bench_bayes.py" --mode fast --no-cpu-baseline >> "$out/${tag}_bench_bayes.json" 2>> "$out/${tag}_bench.err"
-python3 "$root/scripts/run_mcmc.py" --samples 200 > "$out/${tag}_mcmc.json" 2>> "$out/${tag}_bench.err"
-python3 "$root/scripts/run_mcmc.py" --samples 200 --mode fast >> "$out/${tag}_mcmc.json" 2>> "$out/${tag}_bench.err"
-for m in auto exact; do python3 "$root/bench.py" --mode $m --steps 3 --warmup 1 --no-cpu-baseline >> "$out/${tag}_bench_modes.json" 2>> "$out/${tag}_bench.err"; done
-for cfg in "1024 1025" "512 513" "1024 1641" "2048 3201"; do set -- $cfg; python3 "$root/bench.py" --rad-res $1 --kshape $2 --no-cpu-baseline >> "$out/${tag}_bench_other_sizes.json" 2>> "$out/${tag}_bench.err"; done
-python3 "$root/scripts/hbm_calib.py" > "$out/${tag}_hbm_calibration.txt" 2>&1
-python3 "$root/tests/parity_report.py" > "$out/${tag}_parity_report.txt" 2>&1 || true
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$out/${tag}_kt" -o kt --output-format csv -- \
-  python3 "$root/bench.py" --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2>> "$out/${tag}_bench.err"
-cp "$out/${tag}_kt"/*kernel_stats.csv "$out/${tag}_bench_kernel_stats.csv"
-BENCH_NO_PROF=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/${tag}_pmc_fetch" -o pmc --output-format csv -- \
-  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> "$out/${tag}_bench.err"
-BENCH_NO_PROF=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/${tag}_pmc_write" -o pmc --output-format csv -- \
-  python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> "$out/${tag}_bench.err"
-python3 "$root/scripts/hbm_traffic.py" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" "$out/${tag}_hbm_traffic_pmc.json"
-rm -rf "$out/${tag}_kt" "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write"
-echo done
+run() {  # name, rocprof args..., -- program args
+  local name=$1; shift
+  rocprofv3 "$@" > "$out/$name.log" 2>&1 || { echo "rocprofv3 failed for $name"; tail -5 "$out/$name.log"; }
+}
+# 1. kernel-trace statistics of the bench command (HIP-event profiling on, as in the driver's run)
+run bench_stats --kernel-trace --stats -d "$out/bench_stats" -o b --output-format csv -- \
+  python3 "$root/bench.py" --steps 5 --warmup 2 --no-extras --no-cpu-baseline
+# 2. HBM traffic of the same command
+BENCH_NO_PROF=1 run bench_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/bench_fetch" -o p --output-format csv -- \
+  python3 "$root/bench.py" --steps 1 --warmup 1 --no-extras --no-cpu-baseline
+BENCH_NO_PROF=1 run bench_write --kernel-trace --pmc WRITE_SIZE -d "$out/bench_write" -o p --output-format csv -- \
+  python3 "$root/bench.py" --steps 1 --warmup 1 --no-extras --no-cpu-baseline
+python3 "$root/scripts/hbm_traffic.py" "$out/bench_fetch" "$out/bench_write" "$out/bench_hbm_traffic_pmc.json" > "$out/bench_hbm_traffic.txt"
+# 3. the real-wind chains (Carnarvon, R = 2048: full-column pipeline, flags, fold path)
+run rw_stats --kernel-trace --stats -d "$out/rw_stats" -o b --output-format csv -- \
+  python3 "$root/bench_extras.py" real_wind
+run rw_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/rw_fetch" -o p --output-format csv -- \
+  python3 "$root/bench_extras.py" real_wind
+run rw_write --kernel-trace --pmc WRITE_SIZE -d "$out/rw_write" -o p --output-format csv -- \
+  python3 "$root/bench_extras.py" real_wind
+python3 "$root/scripts/hbm_traffic.py" "$out/rw_fetch" "$out/rw_write" "$out/rw_hbm_traffic_pmc.json" > "$out/rw_hbm_traffic.txt"
+find "$out" -name "*kernel_stats.csv" | head
+# keep the merge small: raw traces stay on the box
+find "$out" -name "*kernel_trace.csv" -delete
+find "$out" -name "*counter_collection.csv" -delete
+du -sh "$out"
