@@ -43,7 +43,7 @@ MODEL_P2 = {
 }
 DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8}
 # kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
-PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': 'void k_col_fused<', 'col_inv_b': 'void k_col<1',
+PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': ('void k_col_fused<', 'void k_colfull_day<'), 'col_inv_b': 'void k_col<1',
             'col_inv_a_x2': 'void k_col_fused_multi<false, 2,', 'col_inv_a_x4': 'void k_col_fused_multi<false, 4,',
             'col_inv_a_x8': 'void k_col_fused_multi<false, 8,'}
 
@@ -78,8 +78,9 @@ def pmc_traffic(kernel_class):
     if not files or name is None:
         return None, None
     best = None
+    names = name if isinstance(name, tuple) else (name,)
     for e in json.load(open(files[-1])):
-        if e['kernel'].startswith(name) and (best is None or e['dispatches'] > best['dispatches']):
+        if e['kernel'].startswith(names) and (best is None or e['dispatches'] > best['dispatches']):
             best = e
     if best is None:
         return None, None
