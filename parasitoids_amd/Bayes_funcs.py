@@ -30,71 +30,107 @@ def _unique_days(dframe):
     return np.array(out)
 
 
-def _project(per_day, start_day, collection_day, obs_days):
-    """per_day[day] = population per row item on oviposition day `day`; returns the
-    expected emergences per item and observation date (Bayes_funcs.py:57-90, :116-144)."""
-    nitem = len(per_day[start_day]) if collection_day > start_day else 0
-    emerg_proj = np.zeros((nitem, max_incubation_time))
+def _projection_matrix(start_day, collection_day, obs_days):
+    """W[day - start_day, n]: share of the oviposition of `day` that emerges in the n-th
+    observation interval after the collection (Bayes_funcs.py:57-90, :116-144) -- the
+    incubation-time spread followed by the binning into observation dates, as one matrix, so
+    that expected emergences = per_day.T @ W."""
+    nday = max(collection_day - start_day, 0)
+    emerg = np.zeros((nday, max_incubation_time))
     for day in range(start_day, collection_day):
         max_post_col = day + max_incubation_time - collection_day
         min_post_col = max(0, max_post_col + 1 - incubation_time.size)
         span_len = max_post_col - min_post_col + 1
-        e = np.outer(per_day[day], incubation_time)
-        emerg_proj[:, min_post_col:max_post_col + 1] += e[:, -span_len:]
-    col = obs_days - collection_day
-    out = np.zeros((nitem, len(obs_days)))
-    out[:, 0] = emerg_proj[:, 0:col[0] + 1].sum(axis=1)
+        emerg[day - start_day, min_post_col:max_post_col + 1] += incubation_time[-span_len:]
+    col = np.asarray(obs_days) - collection_day
+    W = np.zeros((nday, len(col)))
+    W[:, 0] = emerg[:, 0:col[0] + 1].sum(axis=1)
     for n, c in enumerate(col[1:]):
-        out[:, n + 1] = emerg_proj[:, col[n] + 1:c + 1].sum(axis=1)
-    return out
+        W[:, n + 1] = emerg[:, col[n] + 1:c + 1].sum(axis=1)
+    return W
+
+
+def _plan(locinfo):
+    """Everything of popdensity_to_emergence / popdensity_grid that depends on the site data
+    only -- collection and observation days, cell lists, field boundaries, projection
+    matrices -- computed once per `locinfo` object (it is static during a sampling run; the
+    per-evaluation work is then one device gather and a few small matrix products)."""
+    plan = getattr(locinfo, '_ps_plan', None)
+    if plan is not None:
+        return plan
+    rel = []
+    for nframe, dframe in enumerate(locinfo.release_DataFrames):
+        collection_day = _days(locinfo.collection_datesPR[nframe])
+        start_day = max(collection_day - max_incubation_time, 0)
+        cells = np.asarray(locinfo.emerg_grids[nframe]).reshape(-1, 2)
+        rel.append(dict(days=list(range(start_day, collection_day)), rows=cells[:, 0], cols=cells[:, 1],
+                        W=_projection_matrix(start_day, collection_day, _unique_days(dframe))))
+    sen = []
+    for nframe, dframe in enumerate(locinfo.sent_DataFrames):
+        collection_day = _days(locinfo.collection_datesPR[nframe])
+        start_day = max(collection_day - max_incubation_time, 0)
+        fields = [np.asarray(locinfo.field_cells[f]) for f in locinfo.sent_ids]
+        sen.append(dict(days=list(range(start_day, collection_day)),
+                        rows=np.concatenate([f[:, 0] for f in fields]),
+                        cols=np.concatenate([f[:, 1] for f in fields]),
+                        starts=np.cumsum([0] + [len(f) for f in fields])[:-1],
+                        empty=np.array([len(f) == 0 for f in fields]),
+                        W=_projection_matrix(start_day, collection_day, _unique_days(dframe))))
+    cells = np.asarray(locinfo.grid_cells)
+    gdays = [_days(date) - 1 for date in locinfo.grid_obs_datesPR]
+    grid = dict(rows=cells[:, 0], cols=cells[:, 1], days=gdays, udays=sorted(set(gdays)))
+    plan = dict(rel=rel, sen=sen, grid=grid)
+    try:
+        locinfo._ps_plan = plan
+    except AttributeError:
+        pass
+    return plan
+
+
+def _gather_matrix(modelsol, days, rows, cols):
+    """[len(days), len(rows)] values at the cells; one device call when the model offers it."""
+    days = list(days)
+    if not days:
+        return np.zeros((0, len(rows)))
+    if hasattr(modelsol, 'gather_days'):
+        return np.asarray(modelsol.gather_days(days, rows, cols))
+    return np.array([modelsol.gather(day, rows, cols) for day in days])
 
 
 def _gather_days(modelsol, days, rows, cols):
     '''{day: values at the cells}; one device call for all days when the model offers it.'''
     days = list(days)
-    if not days:
-        return {}
-    if hasattr(modelsol, 'gather_days'):
-        vals = modelsol.gather_days(days, rows, cols)
-        return {day: vals[n] for n, day in enumerate(days)}
-    return {day: modelsol.gather(day, rows, cols) for day in days}
+    return dict(zip(days, _gather_matrix(modelsol, days, rows, cols)))
 
 
 def popdensity_to_emergence(modelsol, locinfo):
     '''Expected number of wasps per release-field grid point / sentinel field whose
     oviposition results in emergence on each observation date (Bayes_funcs.py:20-152).
     Returns (release_emerg, sentinel_emerg): one array per collection.'''
+    plan = _plan(locinfo)
     release_emerg = []
-    for nframe, dframe in enumerate(locinfo.release_DataFrames):
-        collection_day = _days(locinfo.collection_datesPR[nframe])
-        start_day = max(collection_day - max_incubation_time, 0)
-        cells = np.asarray(locinfo.emerg_grids[nframe]).reshape(-1, 2)
-        per_day = _gather_days(modelsol, range(start_day, collection_day), cells[:, 0], cells[:, 1])
-        release_emerg.append(_project(per_day, start_day, collection_day, _unique_days(dframe)))
+    for fr in plan['rel']:
+        per_day = _gather_matrix(modelsol, fr['days'], fr['rows'], fr['cols'])      # [day, grid point]
+        release_emerg.append(per_day.T @ fr['W'])
     sentinel_emerg = []
-    for nframe, dframe in enumerate(locinfo.sent_DataFrames):
-        collection_day = _days(locinfo.collection_datesPR[nframe])
-        start_day = max(collection_day - max_incubation_time, 0)
-        fields = [np.asarray(locinfo.field_cells[f]) for f in locinfo.sent_ids]
-        rows = np.concatenate([f[:, 0] for f in fields])
-        cols = np.concatenate([f[:, 1] for f in fields])
-        bounds = np.cumsum([0] + [len(f) for f in fields])
-        per_day = {day: np.array([v[bounds[i]:bounds[i + 1]].sum() for i in range(len(fields))])
-                   for day, v in _gather_days(modelsol, range(start_day, collection_day), rows, cols).items()}
-        sentinel_emerg.append(_project(per_day, start_day, collection_day, _unique_days(dframe)))
+    for fr in plan['sen']:
+        vals = _gather_matrix(modelsol, fr['days'], fr['rows'], fr['cols'])         # [day, field cell]
+        if vals.shape[0] and vals.shape[1]:
+            per_day = np.add.reduceat(vals, np.minimum(fr['starts'], vals.shape[1] - 1), axis=1)
+            per_day[:, fr['empty']] = 0.0
+        else:
+            per_day = np.zeros((vals.shape[0], len(fr['starts'])))
+        sentinel_emerg.append(per_day.T @ fr['W'])
     return (release_emerg, sentinel_emerg)
 
 
 def popdensity_grid(modelsol, locinfo):
     '''Expected number of wasps in each grid point on each grid observation date
     (Bayes_funcs.py:156-179); the model holds end-of-day results.'''
-    cells = np.asarray(locinfo.grid_cells)
-    out = np.zeros((cells.shape[0], len(locinfo.grid_obs_datesPR)))
-    days = [_days(date) - 1 for date in locinfo.grid_obs_datesPR]
-    vals = _gather_days(modelsol, sorted(set(days)), cells[:, 0], cells[:, 1])
-    for nday, day in enumerate(days):
-        out[:, nday] = vals[day]
-    return out
+    g = _plan(locinfo)['grid']
+    vals = _gather_matrix(modelsol, g['udays'], g['rows'], g['cols'])
+    index = {day: n for n, day in enumerate(g['udays'])}
+    return vals[[index[day] for day in g['days']]].T.copy()
 
 
 def popdensity_card(modelsol, locinfo, domain_info):

@@ -122,14 +122,42 @@ def initial_sent_obs_probs(locinfo, cell_area):
 
 
 # ------------------------------------------------------------------ likelihood
-def poisson_loglik(obs, rate):
-    """sum over cells of log Poisson(obs | rate); a zero rate only explains zero counts."""
+def poisson_loglik(obs, rate, lgam=None):
+    """sum over cells of log Poisson(obs | rate); a zero rate only explains zero counts.
+    `lgam` = sum of gammaln(obs + 1) when the caller has it (it depends on the data only)."""
     obs = np.asarray(obs, dtype=np.float64)
     rate = np.asarray(rate, dtype=np.float64)
-    if np.any((rate <= 0) & (obs > 0)) or np.any(rate < 0) or not np.all(np.isfinite(rate)):
+    if not np.all(np.isfinite(rate)) or rate.min(initial=0.0) < 0:
         return NEG_INF
     pos = rate > 0
-    return float((obs[pos] * np.log(rate[pos]) - rate[pos] - gammaln(obs[pos] + 1)).sum())
+    if not pos.all():
+        if np.any(obs[~pos] > 0):
+            return NEG_INF
+        g = float(gammaln(obs[pos] + 1).sum())
+        return float((obs[pos] * np.log(rate[pos]) - rate[pos]).sum()) - g
+    if lgam is None:
+        lgam = float(gammaln(obs + 1).sum())
+    return float((obs * np.log(rate) - rate).sum()) - lgam
+
+
+def observation_cache(locinfo):
+    """The data side of the likelihood, prepared once per site object: observation arrays as
+    float64, collection efforts, grid sampling effort and the sums of log(obs!)."""
+    c = getattr(locinfo, '_ps_obs', None)
+    if c is not None:
+        return c
+    f = lambda a: np.asarray(a, dtype=np.float64)
+    c = {'rel': [f(a) for a in locinfo.release_emerg], 'sen': [f(a) for a in locinfo.sentinel_emerg],
+         'grid': f(locinfo.grid_obs), 'effort': [f(a) for a in locinfo.release_collection],
+         'samples': f(locinfo.grid_samples)}
+    c['rel_lg'] = [float(gammaln(a + 1).sum()) for a in c['rel']]
+    c['sen_lg'] = [float(gammaln(a + 1).sum()) for a in c['sen']]
+    c['grid_lg'] = float(gammaln(c['grid'] + 1).sum())
+    try:
+        locinfo._ps_obs = c
+    except AttributeError:
+        pass
+    return c
 
 
 def expected_observations(pop_model, locinfo):
@@ -145,14 +173,15 @@ def loglik_parts(expected, locinfo, nuis, sent_obs_probs):
     grid_obs_prob*samples*density (grid)."""
     rel, sen, grid = expected
     xi, em_p, grid_p = nuis
+    c = observation_cache(locinfo)
     ll_rel = 0.0
     for ii, e in enumerate(rel):
-        effort = np.asarray(locinfo.release_collection[ii], dtype=np.float64)
-        ll_rel += poisson_loglik(locinfo.release_emerg[ii], xi * e * (effort * em_p)[:, None])
+        ll_rel += poisson_loglik(c['rel'][ii], xi * e * (c['effort'][ii] * em_p)[:, None], c['rel_lg'][ii])
     ll_sen = 0.0
+    sp = np.asarray(sent_obs_probs, dtype=np.float64)[:, None]
     for ii, e in enumerate(sen):
-        ll_sen += poisson_loglik(locinfo.sentinel_emerg[ii], xi * e * np.asarray(sent_obs_probs)[:, None])
-    ll_grid = poisson_loglik(locinfo.grid_obs, grid_p * np.asarray(locinfo.grid_samples) * grid)
+        ll_sen += poisson_loglik(c['sen'][ii], xi * e * sp, c['sen_lg'][ii])
+    ll_grid = poisson_loglik(c['grid'], grid_p * c['samples'] * grid, c['grid_lg'])
     return ll_rel, ll_sen, ll_grid
 
 

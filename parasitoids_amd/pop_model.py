@@ -130,14 +130,19 @@ class PopModel():
     def gather(self, day, rows, cols):
         '''Population density at the given cells of one day (what popdensity_grid /
         popdensity_to_emergence read from the daily solutions, Bayes_funcs.py:20-179).'''
-        solver = self.solver
-        scale = float(self.r_number)
-        kind, idx = (L.REC_STATE, 0) if day == 0 else (L.REC_CHAIN, day - 1)
-        return solver.gather(kind, idx, rows, cols, scale=scale, negval=1e-8)
+        return self.gather_days([day], rows, cols)[0]
 
     def gather_days(self, days, rows, cols):
-        '''gather() for several days at once -> [len(days), len(rows)] (one device call).'''
+        '''gather() for several days at once -> [len(days), len(rows)] (one device call): the
+        values `population(day)` holds at those cells -- thresholded at 1e-8 and, for the
+        probability model, with the day's renormalisation delta added to every kept entry
+        (CalcSol.py:134-135).'''
         days = list(days)
         kinds = [L.REC_STATE if d == 0 else L.REC_CHAIN for d in days]
         idxs = [0 if d == 0 else d - 1 for d in days]
-        return self.solver.gather_multi(kinds, idxs, rows, cols, scale=float(self.r_number), negval=1e-8)
+        out = self.solver.gather_multi(kinds, idxs, rows, cols, scale=float(self.r_number), negval=1e-8)
+        if self.prob_model and self.stats is not None:
+            for n, d in enumerate(days):
+                if d > 0:
+                    out[n] = np.where(out[n] != 0.0, out[n] + self.stats[d - 1].delta, 0.0)
+        return out

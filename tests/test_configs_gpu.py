@@ -145,6 +145,12 @@ def test_config5_ensemble_members_against_oracle():
                 assert (diff.max() if diff.nnz else 0.0) < 1e-12, (i, d)
                 assert got.nnz == ref[d].nnz
                 assert abs(got.sum() - 1.0) < 1e-11
+            # point gathers return what population(day) holds, renormalisation included
+            rr = np.array([R, R + 3, R - 40, 5]); cc = np.array([R, R - 2, R + 17, 7])
+            g3 = pm.gather_days([0, 3, nd - 1], rr, cc)
+            for n, d in enumerate((0, 3, nd - 1)):
+                want = np.asarray(pm.population(d)[rr, cc]).ravel()
+                assert np.abs(g3[n] - want).max() < 1e-15
         pm.close()
 
 

@@ -168,3 +168,63 @@ def test_sampler_moves_adapts_and_resumes(golden, tmp_path):
     rest = c.run(25)
     assert np.array_equal(rest['trace'], full['trace'][35:])
     assert np.array_equal(rest['logp'], full['logp'][35:])
+
+
+def test_bayes_funcs_projection_against_a_loop_restatement(golden):
+    """parasitoids_amd.Bayes_funcs turns the model -> emergence translation into one gather and
+    a matrix product per collection (precomputed per site).  Checked here, without a device,
+    against a day-by-day loop that follows the reference's statements (Bayes_funcs.py:57-90,
+    :116-144): incubation spread, then binning into observation dates."""
+    import pandas as pd
+    from parasitoids_amd import Bayes_funcs as BF
+    g = golden('g9_bayes_funcs')
+    td = lambda d: pd.Timedelta(days=int(d))
+    li = types.SimpleNamespace()
+    li.collection_datesPR = [td(d) for d in g['collection_days']]
+    li.emerg_grids = [[tuple(rc) for rc in g['emerg_grid%d' % i]] for i in range(2)]
+    li.release_DataFrames = [pd.DataFrame({'datePR': [td(d) for d in g['rel_dates%d' % i]]}) for i in range(2)]
+    li.sent_DataFrames = [pd.DataFrame({'datePR': [td(d) for d in g['sen_dates%d' % i]]}) for i in range(2)]
+    li.sent_ids = ['A', 'B', 'C']
+    li.field_cells = {k: g['field_' + k] for k in li.sent_ids}
+    li.grid_cells = g['grid_cells']
+    li.grid_obs_datesPR = [td(d) for d in g['grid_obs_days']]
+    rng = np.random.default_rng(3)
+    fields = rng.random((8, 257, 257)) * 1e3
+
+    class Model():
+        def gather(self, day, rows, cols):
+            return fields[day][np.asarray(rows), np.asarray(cols)]
+
+    def loop_project(per_day, start_day, collection_day, obs_days):
+        nitem = len(per_day[start_day]) if collection_day > start_day else 0
+        proj = np.zeros((nitem, BF.max_incubation_time))
+        for day in range(start_day, collection_day):
+            max_post = day + BF.max_incubation_time - collection_day
+            min_post = max(0, max_post + 1 - BF.incubation_time.size)
+            span = max_post - min_post + 1
+            proj[:, min_post:max_post + 1] += np.outer(per_day[day], BF.incubation_time)[:, -span:]
+        col = obs_days - collection_day
+        out = np.zeros((nitem, len(obs_days)))
+        out[:, 0] = proj[:, 0:col[0] + 1].sum(axis=1)
+        for n, c in enumerate(col[1:]):
+            out[:, n + 1] = proj[:, col[n] + 1:c + 1].sum(axis=1)
+        return out
+
+    m = Model()
+    rel, sen = BF.popdensity_to_emergence(m, li)
+    for i in range(2):
+        cday = int(g['collection_days'][i])
+        sday = max(cday - BF.max_incubation_time, 0)
+        cells = np.asarray(li.emerg_grids[i])
+        per = {d: m.gather(d, cells[:, 0], cells[:, 1]) for d in range(sday, cday)}
+        ref = loop_project(per, sday, cday, np.unique(g['rel_dates%d' % i]))
+        np.testing.assert_allclose(rel[i], ref, rtol=1e-13, atol=1e-9)
+        per = {d: np.array([m.gather(d, li.field_cells[k][:, 0], li.field_cells[k][:, 1]).sum() for k in li.sent_ids])
+               for d in range(sday, cday)}
+        ref = loop_project(per, sday, cday, np.unique(g['sen_dates%d' % i]))
+        np.testing.assert_allclose(sen[i], ref, rtol=1e-13, atol=1e-9)
+        assert rel[i].shape == g['rel%d' % i].shape and sen[i].shape == g['sen%d' % i].shape
+    grid = BF.popdensity_grid(m, li)
+    for n, d in enumerate(g['grid_obs_days']):
+        assert np.array_equal(grid[:, n], fields[int(d) - 1][li.grid_cells[:, 0], li.grid_cells[:, 1]])
+    assert getattr(li, '_ps_plan', None) is not None          # the site plan is cached on the object
