@@ -80,6 +80,15 @@ def _plan(locinfo):
     gdays = [_days(date) - 1 for date in locinfo.grid_obs_datesPR]
     grid = dict(rows=cells[:, 0], cols=cells[:, 1], days=gdays, udays=sorted(set(gdays)))
     plan = dict(rel=rel, sen=sen, grid=grid)
+    # one gather for everything: the union of the days, all cell lists back to back
+    parts = rel + sen + [dict(days=grid['udays'], rows=grid['rows'], cols=grid['cols'])]
+    udays = sorted(set(d for p in parts for d in p['days']))
+    pos = {d: n for n, d in enumerate(udays)}
+    off = np.cumsum([0] + [len(p['rows']) for p in parts])
+    plan['all'] = dict(days=udays, rows=np.concatenate([np.asarray(p['rows']) for p in parts]).astype(np.int32),
+                       cols=np.concatenate([np.asarray(p['cols']) for p in parts]).astype(np.int32),
+                       slices=[(np.array([pos[d] for d in p['days']], dtype=int), int(off[i]), int(off[i + 1]))
+                               for i, p in enumerate(parts)])
     try:
         locinfo._ps_plan = plan
     except AttributeError:
@@ -122,6 +131,35 @@ def popdensity_to_emergence(modelsol, locinfo):
             per_day = np.zeros((vals.shape[0], len(fr['starts'])))
         sentinel_emerg.append(per_day.T @ fr['W'])
     return (release_emerg, sentinel_emerg)
+
+
+def expected_observations(modelsol, locinfo):
+    """(release_emerg, sentinel_emerg, grid_counts) -- popdensity_to_emergence and popdensity_grid
+    (Bayes_Run.py:325-336) from ONE device gather: every cell list of the site against the union
+    of the days any of them needs, sliced on the host."""
+    plan = _plan(locinfo)
+    if not hasattr(modelsol, 'gather_days'):
+        rel, sen = popdensity_to_emergence(modelsol, locinfo)
+        return rel, sen, popdensity_grid(modelsol, locinfo)
+    al = plan['all']
+    vals = np.asarray(modelsol.gather_days(al['days'], al['rows'], al['cols']))
+    blocks = [vals[np.ix_(didx, np.arange(lo, hi))] if len(didx) else np.zeros((0, hi - lo))
+              for didx, lo, hi in al['slices']]
+    nrel, nsen = len(plan['rel']), len(plan['sen'])
+    release_emerg = [blocks[i].T @ plan['rel'][i]['W'] for i in range(nrel)]
+    sentinel_emerg = []
+    for i, fr in enumerate(plan['sen']):
+        v = blocks[nrel + i]
+        if v.shape[0] and v.shape[1]:
+            per_day = np.add.reduceat(v, np.minimum(fr['starts'], v.shape[1] - 1), axis=1)
+            per_day[:, fr['empty']] = 0.0
+        else:
+            per_day = np.zeros((v.shape[0], len(fr['starts'])))
+        sentinel_emerg.append(per_day.T @ fr['W'])
+    g = plan['grid']
+    index = {day: n for n, day in enumerate(g['udays'])}
+    grid = blocks[-1][[index[day] for day in g['days']]].T.copy()
+    return release_emerg, sentinel_emerg, grid
 
 
 def popdensity_grid(modelsol, locinfo):

@@ -161,10 +161,8 @@ def observation_cache(locinfo):
 
 
 def expected_observations(pop_model, locinfo):
-    """(release_emerg, sentinel_emerg, grid_counts) of Bayes_Run.py:325-336."""
-    rel, sen = BF.popdensity_to_emergence(pop_model, locinfo)
-    grid = BF.popdensity_grid(pop_model, locinfo)
-    return rel, sen, grid
+    """(release_emerg, sentinel_emerg, grid_counts) of Bayes_Run.py:325-336 (one device gather)."""
+    return BF.expected_observations(pop_model, locinfo)
 
 
 def loglik_parts(expected, locinfo, nuis, sent_obs_probs):
@@ -415,7 +413,7 @@ class Sampler():
         if self._evaluate_fn is not None:
             return self._evaluate_fn(theta)
         try:
-            self.pm.evaluate(*model_args(theta), ndays=self.ndays)
+            self.pm.evaluate(*model_args(theta), ndays=self.ndays, want_stats=False)
         except (AssertionError, ValueError, RuntimeError):
             self.n_failed += 1
             return None

@@ -82,9 +82,12 @@ class PopModel():
         self._solvers[key] = s          # most recently used last
         return s
 
-    def evaluate(self, hparams, Dparams, Dlparams, mu_r, n_periods, ndays=None):
+    def evaluate(self, hparams, Dparams, Dlparams, mu_r, n_periods, ndays=None, want_stats=True):
         '''One model evaluation; results stay on the device.  Returns the per-day
-        statistics [(nnz, total population above 1e-8), ...], day 0 first.'''
+        statistics [(nnz, total population above 1e-8), ...], day 0 first -- or None with
+        want_stats=False: the chain is then only enqueued (no host synchronisation; a sampler
+        that reads nothing but point gathers does not need the statistics, `self.stats` and
+        `population()` fetch them on demand).'''
         nd = len(self.days) if ndays is None else ndays
         starts = [self.r_start] + [None] * (nd - 1)
         kshape, nnz, warned, status = self.model.build(
@@ -95,14 +98,26 @@ class PopModel():
         solver = self._solver_for(int(kshape.max()))
         self.solver = solver
         scale = float(self.r_number)          # dist(1) = 1 for a one-day release
-        st0 = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
-        out = [(st0.nnz, st0.sum * scale)]
+        self._nd = nd
+        self._stats = None
         if nd > 1:
             solver.set_kernels_from_model(self.model, 1, nd - 1)
             solver.run_chain(0, nd - 1, negval=1e-8, scale=scale, renorm=self.prob_model)
-            self.stats = solver.chain_stats(0, nd - 1)
-            out += [(s.nnz, s.sum) for s in self.stats]
-        return out
+        if not want_stats:
+            return None
+        st0 = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
+        return [(st0.nnz, st0.sum * scale)] + [(s.nnz, s.sum) for s in self.stats]
+
+    @property
+    def stats(self):
+        '''per-day statistics of the chain days of the last evaluation (synchronises)'''
+        if self._stats is None and self.solver is not None and getattr(self, '_nd', 0) > 1:
+            self._stats = self.solver.chain_stats(0, self._nd - 1)
+        return self._stats if self._stats is not None else []
+
+    @stats.setter
+    def stats(self, value):
+        self._stats = value
 
     def population(self, day):
         '''Day `day` (0 = release day) of the last evaluation as a csr matrix, the value
@@ -141,7 +156,7 @@ class PopModel():
         kinds = [L.REC_STATE if d == 0 else L.REC_CHAIN for d in days]
         idxs = [0 if d == 0 else d - 1 for d in days]
         out = self.solver.gather_multi(kinds, idxs, rows, cols, scale=float(self.r_number), negval=1e-8)
-        if self.prob_model and self.stats is not None:
+        if self.prob_model and self.stats:
             for n, d in enumerate(days):
                 if d > 0:
                     out[n] = np.where(out[n] != 0.0, out[n] + self.stats[d - 1].delta, 0.0)

@@ -228,3 +228,17 @@ def test_bayes_funcs_projection_against_a_loop_restatement(golden):
     for n, d in enumerate(g['grid_obs_days']):
         assert np.array_equal(grid[:, n], fields[int(d) - 1][li.grid_cells[:, 0], li.grid_cells[:, 1]])
     assert getattr(li, '_ps_plan', None) is not None          # the site plan is cached on the object
+
+    # the one-gather form a device model gets: same numbers
+    class Model2(Model):
+        calls = 0
+
+        def gather_days(self, days, rows, cols):
+            Model2.calls += 1
+            return np.array([fields[d][np.asarray(rows), np.asarray(cols)] for d in days])
+    rel2, sen2, grid2 = BF.expected_observations(Model2(), li)
+    assert Model2.calls == 1
+    for i in range(2):
+        np.testing.assert_allclose(rel2[i], rel[i], rtol=1e-14, atol=1e-10)
+        np.testing.assert_allclose(sen2[i], sen[i], rtol=1e-14, atol=1e-10)
+    assert np.array_equal(grid2, grid)
