@@ -74,6 +74,18 @@ size_t round_size(size_t b) {
 }
 }  // namespace
 
+// PS_POISON=1 (test aid): every block handed out is filled with 0xFF bytes -- NaNs as doubles,
+// -1 as integers -- so that a pass reading rows "known to be zero" that nobody wrote (the
+// passes skip dead rows on both sides) shows up deterministically instead of only when the
+// caching allocator happens to recycle a dirty block.
+static hipError_t poison(void* p, size_t n) {
+  static const bool on = getenv("PS_POISON") != nullptr;
+  if (!on) return hipSuccess;
+  hipError_t e = hipMemset(p, 0xFF, n);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e;
+}
+
 hipError_t ps_dev_malloc(void** out, size_t bytes) {
   DevPool& P = pool();
   int dev = 0;
@@ -86,8 +98,9 @@ hipError_t ps_dev_malloc(void** out, size_t bytes) {
     *out = it->second;
     P.live[*out] = {dev, it->first};
     P.cached -= it->first;
+    const size_t got = it->first;
     fr.erase(it);
-    return hipSuccess;
+    return poison(*out, got);
   }
   hipError_t e = hipMalloc(out, want);
   if (e != hipSuccess) {   // give the cached blocks back and try once more
@@ -95,7 +108,10 @@ hipError_t ps_dev_malloc(void** out, size_t bytes) {
     P.flush_locked();
     e = hipMalloc(out, want);
   }
-  if (e == hipSuccess) P.live[*out] = {dev, want};
+  if (e == hipSuccess) {
+    P.live[*out] = {dev, want};
+    e = poison(*out, want);
+  }
   return e;
 }
 
@@ -1431,11 +1447,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   // kernels on a split column transform do best in the tiled pipeline (multi-day fused passes
   // with direct-sum kernels: 2650 against 2420 grid-days/s on the synthetic N = 4097 stack);
   // everything else -- broad prob_mass kernels, flagged days -- in the full-column pipeline
-  // (Carnarvon R = 2048: 1040 -> 1440 grid-days/s).  Single-pass column sizes keep the tiled one.
+  // (Carnarvon R = 2048: 1040 -> 1440 grid-days/s).
   if (s->tpipe_ok && !s->spec_valid) {
     bool compact = direct_possible(s);
     for (int d = first; d < first + count && compact; ++d) compact = day_is_compact(s, d);
-    bool want = s->split && !compact;
+    bool want = !(s->split && compact);   // single-pass column sizes too: +6 % on the flag-heavy R = 400 Bayes chain
     if (const char* e = getenv("PS_TPIPE")) want = atoi(e) != 0;   // A/B knob
     set_pipeline(s, want);
   }
@@ -1656,7 +1672,7 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
       B = s->Fhat.p + (size_t)slot * spec;
       // what fwd2d_partial leaves behind for the fused pass that consumes B
       s->kt_direct = false;
-      s->kt_live = s->split ? RowLive{0, {0, 0, 0, 0}, nullptr} : RowLive{1, map_wrap(M, s->Pf), nullptr};
+      s->kt_live = (s->split && !s->tpipe) ? RowLive{0, {0, 0, 0, 0}, nullptr} : RowLive{1, map_wrap(M, s->Pf), nullptr};
     } else {
       ++s->filt_misses;
       cplx* dst = s->Bhat.p;

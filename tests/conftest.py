@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+# Every device block the library hands out during the tests is pre-filled with NaN bytes
+# (PS_POISON, read at the first allocation): the FFT passes skip rows that are known to be zero
+# on the writing AND the reading side, and a mismatch between the two would otherwise only show
+# when the caching allocator recycles a dirty block.
+os.environ.setdefault('PS_POISON', '1')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
     # the shared library is a build artefact (git-ignored): build it if this checkout has none
