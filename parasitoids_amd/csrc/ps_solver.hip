@@ -765,7 +765,17 @@ static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, d
   if (s->tpipe) {
     RowLive live = s->kt_live;
     live.range = rowrange;
-    PS_TRY(launch_colfull(s, 0, kt, state, store_prod, s->T1.p, 1, live, nullptr));
+    static const int split2 = getenv("PS_TPIPE_SPLIT") ? atoi(getenv("PS_TPIPE_SPLIT")) : 0;   // A/B knob
+    if (split2 && store_prod) {
+      // two passes at <= 128 registers (two workgroups per CU each) instead of one at 162:
+      // product into the state, then the inverse of the state.  Measured: 2 x 159 us against
+      // 255-265 us for the single pass at 5184 -- the row-major 16-byte stores, not the
+      // occupancy, are what the day pass waits for.  Off.
+      PS_TRY(launch_colfull(s, 3, kt, state, 1, nullptr, 1, live, nullptr));
+      PS_TRY(launch_colfull(s, 2, nullptr, state, 0, s->T1.p, 1, RowLive{0, {0, 0, 0, 0}, nullptr}, nullptr));
+    } else {
+      PS_TRY(launch_colfull(s, 0, kt, state, store_prod, s->T1.p, 1, live, nullptr));
+    }
     return launch_row_inv(s, s->T1.p, rec, stat_slot, 1, negval, stat_scale);
   }
   int done = 0;
