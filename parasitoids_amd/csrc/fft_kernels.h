@@ -383,6 +383,7 @@ struct ColFusedArgs {
   // kernel's first column sub-pass is evaluated as a direct sum over its few live rows
   // (kt_direct_fill); tp_* = two-level twiddle table of w_N, N = L1 L2; mgL2 = ps_magic(L2)
   int direct;
+  int no_conj;       // A/B knob PS_NO_CONJ: direct fill of a conjugate pair with two twiddle tables
   const cplx* tp_lo;
   const cplx* tp_hi;
   int tp_shift;
@@ -812,7 +813,7 @@ __global__ void k_col_fused_multi(ColFusedArgs a) {
   const int totg = L << (a.wsh + GSH), totn = L << wshn;
   if (a.direct) {
     __syncthreads();
-    if (G == 2) kt_direct_fill_pair<ND>(a, data, stw, wj, c0, wshn, ent, oq != 0);
+    if (G == 2) kt_direct_fill_pair<ND>(a, data, stw, wj, c0, wshn, ent, oq != 0 && !a.no_conj);
     else kt_direct_fill<1>(a, data, stw, wj, c0, wshn, NDSH, nullptr);
   } else
   for (int idx0 = threadIdx.x; idx0 < totn; idx0 += nthr * PS_UNROLL) {

@@ -609,6 +609,8 @@ static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, i
 
 static void fused_direct_args(ps_solver* s, ColFusedArgs& a) {
   a.direct = s->kt_direct ? 1 : 0;
+  static const int no_conj = getenv("PS_NO_CONJ") ? 1 : 0;
+  a.no_conj = no_conj;
   a.tp_lo = s->tp_lo.p; a.tp_hi = s->tp_hi.p; a.tp_shift = s->tp_shift;
   a.mgL2 = ps_magic((uint32_t)a.L2);
 }
