@@ -45,6 +45,7 @@ struct ColFullArgs {
   int64_t dst_bstride;
   int ld, ncols, mode, store_prod;
   int nd;                // mode 0: consecutive days in this pass
+  int dst_t;             // dst is column-major [H][L] too (the inverse row pass reads it that way)
   int64_t src_dstride, dst_dstride;   // per day
   RowLive live;          // rows of src that were never written (known zero); range advances 2 ints per day
   const unsigned long long* pred;
@@ -131,9 +132,10 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
   if (j < S::T1) bfly<R1, PS_INV>(x);
   rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);     // thread j < T3: spatial rows j + q T3
   if (j < S::T3) {
-    cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + c;
+    cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (a.dst_t ? (int64_t)c * L : (int64_t)c);
+    const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
 #pragma unroll
-    for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * a.ld] = x[q];
+    for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = x[q];
   }
 }
 
@@ -174,9 +176,10 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
     }
     rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
     if (j < S::T3) {
-      cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + c;
+      cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (a.dst_t ? (int64_t)c * L : (int64_t)c);
+      const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
 #pragma unroll
-      for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * a.ld] = x[q];
+      for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = x[q];
     }
   } else if constexpr (MODE == 1) {    // forward: row-pass output column -> state column
     cplx x[S::RMAX];
@@ -263,9 +266,11 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
         if (jv < S::T1) bfly<R1, PS_INV>(x);
         rs_tail<S, R1, R2, R3, PS_INV>(x, ex, jv, w2, w3);     // thread jv < T3: spatial rows jv + q T3
         if (jv < S::T3) {
-          cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)day * a.dst_dstride + c;
+          cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)day * a.dst_dstride +
+                    (a.dst_t ? (int64_t)c * L : (int64_t)c);
+          const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
 #pragma unroll
-          for (int q = 0; q < R3; ++q) d[(int64_t)(jv + q * S::T3) * a.ld] = x[q];
+          for (int q = 0; q < R3; ++q) d[(int64_t)(jv + q * S::T3) * rst] = x[q];
         }
         if (day + 1 < nd) __syncthreads();   // the exchange buffer is reused by the next day's transform
       }

@@ -91,6 +91,7 @@ struct RowInvArgs {
   const cplx* src;
   int64_t src_bstride;
   int H, ld, P, N;
+  int tstride;   // != 0 (register-resident kernel only): src is column-major [H][tstride] (full-column pipeline)
   int rp;
   double scale;  // 1 / Pfft^2
   double* rec;   // [N][N] raw real solution

@@ -32,16 +32,27 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   // Reverse dispatch order: the cheap pad-only pairs (top rows, mostly skipped) and the odd
   // last domain row go first, so the equally long domain workgroups that follow end together
   // instead of leaving one straggler for an extra round.
-  const int pair = ((int)gridDim.x - 1 - (int)blockIdx.x) * NP + half;
-  if (2 * pair >= a.P) return;   // ended waves do not take part in the barriers below
+  int unit = (int)blockIdx.x;
+  if (a.tstride) {
+    // column-major input: a 128-byte line holds 8 rows = 4 / NP workgroups' worth; they are
+    // consecutive blocks of ONE XCD, so the line comes from HBM once and the other readers
+    // find it in that L2 (gridDim.x is a multiple of 8 * (4 / NP))
+    constexpr int KL = NP >= 4 ? 1 : 4 / NP;
+    const int xcd = unit & 7, q = unit >> 3;
+    unit = ((q / KL) * 8 + xcd) * KL + (q % KL);
+  }
+  const int pair = ((int)gridDim.x - 1 - unit) * NP + half;
+  if (2 * pair >= a.P || pair < 0) return;   // ended waves do not take part in the barriers below
   double* ex = reinterpret_cast<double*>(ps_lds_raw) + half * (Y::XW + Y::RED);
   double* red = ex + Y::XW;      // 5 * NW doubles
   const int j = threadIdx.x - half * S::NTHR, lane = j & 63, wave = j >> 6;
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   const int ra = 2 * pair, rb = ra + 1;
   const bool hasb = rb < a.P;
-  const cplx* pa = src + (int64_t)ra * a.ld;
-  const cplx* pb = src + (int64_t)(hasb ? rb : ra) * a.ld;
+  // element k of row r: row-major at r * ld + k, column-major at k * tstride + r
+  const int64_t kst = a.tstride ? (int64_t)a.tstride : 1;
+  const cplx* pa = src + (a.tstride ? (int64_t)ra : (int64_t)ra * a.ld);
+  const cplx* pb = src + (a.tstride ? (int64_t)(hasb ? rb : ra) : (int64_t)(hasb ? rb : ra) * a.ld);
   const bool pad_only = ra >= a.N;
   const FftProg& P = a.prog;
   const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
@@ -56,12 +67,12 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
       return direct ? i : (unsigned)L - i;
     };
 #pragma unroll
-    for (int q = 0; q < R1; ++q) x[q] = pa[idx(q)];
+    for (int q = 0; q < R1; ++q) x[q] = pa[idx(q) * kst];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       cplx B[R1 / 2];
 #pragma unroll
-      for (int u = 0; u < R1 / 2; ++u) B[u] = pb[idx(h * (R1 / 2) + u)];   // pb aliases row a when there is no row b
+      for (int u = 0; u < R1 / 2; ++u) B[u] = pb[idx(h * (R1 / 2) + u) * kst];   // pb aliases row a when there is no row b
 #pragma unroll
       for (int u = 0; u < R1 / 2; ++u) {
         const int q = h * (R1 / 2) + u;

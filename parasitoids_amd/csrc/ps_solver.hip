@@ -164,6 +164,12 @@ struct ps_solver {
   // front of auto mode); the tiled two-sub-pass column kernels serve every other case.
   bool tpipe = false;
   bool tpipe_ok = false;    // the solver CAN run the full-column pipeline (register-resident size, fast mode)
+  // A/B knob PS_TINV=1: the full-column pass writes its output column-major too (contiguous)
+  // and the inverse row pass does the transposition on its READ side.  Measured at 5184: day
+  // pass 264 -> 237 us, chained 218 -> 186 us per day, but the row pass 145 -> 252 us (32-byte
+  // pieces at a column's stride per lane): a net loss, so the column pass keeps its 16-byte
+  // row-major stores.  It also shows what those stores cost the day pass: 27 us of 264.
+  bool tinv = getenv("PS_TINV") ? atoi(getenv("PS_TINV")) != 0 : false;
   // The state's spectrum is built lazily from its spatial record (PS_REC_STATE), in the layout
   // of the pipeline the first consumer picks: ps_chain_run takes the tiled pipeline for compact
   // day kernels (multi-day fused passes with direct-sum kernels) and the full-column one
@@ -460,6 +466,7 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   RowInvArgs a;
   a.src = src; a.src_bstride = (int64_t)s->Pf * s->ld;
   a.H = s->H; a.ld = s->ld; a.P = s->Pf; a.N = s->N;
+  a.tstride = (s->tpipe && s->tinv && !full_field) ? s->Pf : 0;   // full-column pipeline: column-major intermediate
   a.prog = s->row_plan.prog;
   a.rp = row_pairs(a.prog);
   a.scale = 1.0 / ((double)s->Pf * (double)s->Pf);
@@ -489,7 +496,9 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
       using C = RsCfg<A, B>;                                                                                 \
       constexpr int np = C::NP;                                                                              \
       auto kern = k_row_inv_rs<16, A, B, np>;                                                                \
-      hipLaunchKernelGGL(kern, dim3((npairs + np - 1) / np, batch), dim3(C::S::NTHR * np), C::LDS, s->stream, a); \
+      int gx = (npairs + np - 1) / np;                                                                       \
+      if (a.tstride) { const int m = 8 * (np >= 4 ? 1 : 4 / np); gx = (gx + m - 1) / m * m; }               \
+      hipLaunchKernelGGL(kern, dim3(gx, batch), dim3(C::S::NTHR * np), C::LDS, s->stream, a);                 \
     }
     PS_RS_SIZES(X)
 #undef X
@@ -515,6 +524,7 @@ static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, 
   a.dst = dst; a.dst_bstride = spec;
   a.ld = s->ld; a.ncols = s->H; a.mode = mode; a.store_prod = store_prod;
   a.nd = nd; a.src_dstride = spec; a.dst_dstride = spec;
+  a.dst_t = s->tinv ? 1 : 0;
   a.live = live;
   a.pred = pred;
   a.prog = s->row_plan.prog;
