@@ -307,3 +307,50 @@ def test_auto_mode_routes(hip_lib):
         for d in range(nd):      # run 2 and 3 both start from the remembered hint: identical
             assert np.array_equal(outs[1][d], outs[2][d])
         s.close()
+
+
+def test_flag_speculation_is_exact_in_the_full_column_pipeline(hip_lib, monkeypatch):
+    '''The same property as test_flag_speculation_is_exact on a register-resident FFT size in fast
+    mode with the full-column pipeline forced: un-flagged days run in chained groups (state column
+    parked in LDS), a flag inside a group rolls the chain back to single-day passes with the
+    predicated full-column re-FFT -- bit-identical to the non-speculative chain, wherever the
+    first flag falls.'''
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    R, K, nd = 400, 401, 12
+    N = 2 * R + 1
+    for start in (400, 730, 785):          # no flag at all / first flag late / early
+        _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        runs = []
+        for spec in (True, False):
+            if spec:
+                monkeypatch.delenv('PS_NO_SPECULATION', raising=False)
+            else:
+                monkeypatch.setenv('PS_NO_SPECULATION', '1')
+            s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+            assert s.fft_len == 1008
+            s.set_kernels(kernels)
+            s.prof_enable(True, every=1)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            prof = s.prof_read()
+            assert s.full_column
+            if spec and start == 400:
+                assert prof['col_inv_a_x2'][1] + prof['col_inv_a_x4'][1] + prof['col_inv_a_x8'][1] >= 2   # chained groups ran
+            runs.append(([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st]))
+            s.close()
+        flags = [f for f, _, _, _ in runs[1][1]]
+        assert runs[0][1] == runs[1][1]
+        for a, b in zip(runs[0][0], runs[1][0]):
+            assert np.array_equal(a, b)
+        if start == 400:
+            assert not any(flags)
+        else:
+            assert any(flags)
+        # and against the oracle (fast torus: the domain part agrees to the fast-mode tolerance)
+        ref, trace = [state], {}
+        OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, np.array([K, K]), trace=trace)
+        for d in range(nd):
+            assert np.abs(runs[0][0][d] - trace['raw'][d]).max() < 5e-8
+            assert bool(flags[d]) == bool(trace['flags'][d])
