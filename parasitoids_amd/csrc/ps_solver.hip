@@ -938,9 +938,10 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
   if (getenv("PS_NO_RS") == nullptr && !rs_lookup(s->Pf, &s->rs_r2, &s->rs_r3)) s->rs_r2 = s->rs_r3 = 0;
-  s->tpipe_ok = mode == PS_MODE_FAST && s->rs_r2 != 0 && getenv("PS_NO_RS") == nullptr &&
+  s->tpipe_ok = (mode == PS_MODE_FAST || mode == PS_MODE_FOLD) && s->rs_r2 != 0 && getenv("PS_NO_RS") == nullptr &&
                 getenv("PS_NO_RS_FWD") == nullptr && getenv("PS_NO_TPIPE") == nullptr;
-  s->tpipe = s->tpipe_ok;
+  if (mode == PS_MODE_FOLD && getenv("PS_NO_FOLD_TPIPE")) s->tpipe_ok = false;   // A/B knob
+  s->tpipe = s->tpipe_ok;   // fold mode: always the full-column pipeline when its size allows (no compact-kernel route there)
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;
@@ -1402,6 +1403,25 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       for (int d = c0; d < c0 + cn; ++d) {
         const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
         const SrcMap tmap = map_plain(s->Pref, s->Pf);
+        if (s->tpipe) {
+          // full-column pipeline: state row pass (column-major out) -> one forward column pass ->
+          // day pass (kernel column x state column -> inverse; the product is not kept: the state
+          // lives in space) -> row pass to the full linear-convolution field -> fold
+          PS_TRY(launch_row_fwd(s, s->torus.p, 0, s->Pref, tmap, tmap, s->T1.p, 1, nullptr, 1));
+          PS_TRY(launch_colfull(s, 1, s->T1.p, s->Ahat.p, 0, nullptr, 1, RowLive{1, tmap, nullptr}, nullptr));
+          RowLive klive = s->kt_live;
+          klive.range = s->krange.p + 2 * d;
+          PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr));
+          PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
+          hipLaunchKernelGGL(k_fold, dim3(s->Pref), dim3(256), 0, s->stream, s->lin.p, s->Pf, s->Pref, s->N, s->M,
+                             s->torus.p, s->recs[PS_REC_CHAIN][d], negval, stat_scale,
+                             s->rowsum.p + (int64_t)d * s->N, s->rowcnt.p + (int64_t)d * s->N, s->padmax.p + d);
+          PS_HIP(hipGetLastError());
+          hipLaunchKernelGGL(k_truncate_if_flag, dim3(s->Pref), dim3(256), 0, s->stream, s->torus.p, s->Pref, s->N,
+                             s->padmax.p + d);
+          PS_HIP(hipGetLastError());
+          continue;
+        }
         // state: row pass (+ first column sub-pass); its last forward sub-pass runs inside the
         // fused kernel next to the kernel's
         PS_TRY(launch_row_fwd(s, s->torus.p, 0, s->Pref, tmap, tmap, s->T1.p, 1, nullptr, 1));
