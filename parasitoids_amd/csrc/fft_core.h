@@ -379,6 +379,8 @@ PS_HD void bfly(cplx* x) {
   else if (R == 16) bfly16<DIR>(x);
   else if (R == 18) bfly18<DIR>(x);
   else if (R == 20) bfly_pfa<4, 5, DIR>(x);
+  else if (R == 21) bfly_pfa<3, 7, DIR>(x);
+  else if (R == 24) bfly_pfa<3, 8, DIR>(x);
   else if (R == 25) bfly25<DIR>(x);
 }
 

@@ -171,7 +171,10 @@ int main(int argc, char** argv) {
                      run_rs<16, 18, 9, PS_INV>(), run_rs<16, 9, 9, PS_INV>(),
                      run_rs<16, 10, 12, PS_FWD>(), run_rs<16, 14, 15, PS_INV>(), run_rs<16, 20, 18, PS_FWD>(),
                      run_rs<16, 15, 20, PS_INV>(), run_rs<16, 12, 7, PS_FWD>(),
-                     run_rs<16, 25, 18, PS_FWD>(), run_rs<16, 25, 25, PS_INV>(), run_rs<16, 25, 16, PS_INV>()}) {
+                     run_rs<16, 25, 18, PS_FWD>(), run_rs<16, 25, 25, PS_INV>(), run_rs<16, 25, 16, PS_INV>(),
+                     // radices 21 = 3 x 7 and 24 = 3 x 8 (round 2)
+                     run_rs<16, 21, 7, PS_FWD>(), run_rs<16, 21, 16, PS_INV>(), run_rs<16, 24, 18, PS_FWD>(),
+                     run_rs<16, 25, 21, PS_INV>(), run_rs<16, 24, 24, PS_FWD>(), run_rs<16, 21, 21, PS_INV>()}) {
       if (e < 0) return 2;
       worst = e > worst ? e : worst;
     }
