@@ -81,6 +81,8 @@ def real_wind_case(rad_dist, R=2048, nd=30, mode='fast', device=None, reps=3, pr
            'kernels_direct': bool(s.kernels_direct),
            'auto_first_fold_day': s.auto_info()[0] if s.mode == 'auto' else None,
            'auto_fold_fft': s.auto_info()[1] if s.mode == 'auto' else None,
+           'auto_route_days': ({k: int((s.auto_route(0, nd - 1) == v).sum()) for k, v in
+                                (('front', 0), ('wide', 1), ('fold', 2))} if s.mode == 'auto' else None),
            'multi_day_launches': {k: v['launches_per_chain'] for k, v in kern.items() if k.startswith('col_inv_a_x')},
            'end_to_end_eval_s': round(t_eval, 4), 'first_eval_s': round(t_first, 3),
            'last_day_mass': round(last.sum + last.delta * last.nnz, 12), 'last_day_nnz': int(last.nnz),

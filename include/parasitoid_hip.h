@@ -46,9 +46,12 @@ extern "C" {
 #define PS_MODE_AUTO 3  /* exact reference-torus results by the cheapest route, chain API only: the
                          * day chain runs on the PS_MODE_FAST torus for as long as nothing above
                          * 1e-15 lies outside the N x N domain (then the two tori cannot differ by
-                         * more than that per day: the pad holds no dust to wrap around), and from
-                         * the first day that does it continues as PS_MODE_FOLD from the last
-                         * clean day's field.  ps_solver_auto_info tells which days ran where. */
+                         * more than that per day: the pad holds no dust to wrap around).  Past
+                         * that prefix, days that start from a domain-supported field and end
+                         * flagged (largest value outside the domain > 1e-8) or clean run on a
+                         * fast torus sized N + 2M, where they are true linear convolutions; the
+                         * days in between -- sub-threshold dust the reference carries around its
+                         * torus -- run as PS_MODE_FOLD.  ps_solver_auto_route tells which. */
 
 typedef struct ps_solver ps_solver;
 typedef struct ps_model ps_model;
@@ -97,6 +100,10 @@ int ps_solver_pipeline(ps_solver* s);
  * reference torus (-1: every day was clean and ran on the fast torus); *fold_fft = FFT size of the
  * fold path (0 if it was never needed).  Other modes: -1 / 0. */
 int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_fft);
+/* PS_MODE_AUTO: which solver produced each day [first, first+count) of the last ps_chain_run:
+ * 0 the fast-torus front (clean prefix), 1 the wide fast-torus helper (N + 2M: flagged and clean
+ * days past the prefix), 2 the fold child (days whose sub-threshold dust the reference carries). */
+int ps_solver_auto_route(ps_solver* s, int first, int count, int32_t* owner);
 
 /* CudaSolve.__init__ (cuda_lib.py:34-54) / CalcSol.fft2 (CalcSol.py:11-24):
  * state_hat = FFT2(zero-padded N x N sparse field). */

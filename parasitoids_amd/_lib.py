@@ -74,6 +74,7 @@ SIGNATURES = {
     'ps_solver_kernels_direct': (C.c_int, [_VP]),
     'ps_solver_pipeline': (C.c_int, [_VP]),
     'ps_solver_auto_info': (C.c_int, [_VP, _I32P, _I32P]),
+    'ps_solver_auto_route': (C.c_int, [_VP, C.c_int, C.c_int, _I32P]),
     'ps_record_fetch_coo': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                       C.c_double, _I32P, _I32P, _F64P, C.c_int64, _I64P]),
     'ps_record_fetch_csr': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,

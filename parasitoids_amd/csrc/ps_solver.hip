@@ -228,9 +228,12 @@ struct ps_solver {
   // child shares this solver's stream, chain records and statistics slots' meaning (day index).
   bool auto_exact = false;
   double pad_floor = 0.5e-8;   // inverse row pass publishes pad maxima above this
-  ps_solver* child = nullptr;
-  bool borrowed = false;       // child: stream and chain records belong to the parent
-  bool child_kernels = false;  // child holds the current day kernels
+  ps_solver* child = nullptr;  // fold-mode helper (the reference torus itself)
+  ps_solver* wide = nullptr;   // fast-torus helper sized N + 2M (flagged and clean days past the clean prefix)
+  bool borrowed = false;       // helper: stream and chain records belong to the parent
+  bool child_kernels = false, wide_kernels = false;   // the helper holds the current day kernels
+  std::vector<signed char> owner;   // per chain day of the last run: 0 this solver, 1 wide, 2 child
+  int auto_first_regime = 2;        // helper the last hand-over started with (1 wide, 2 child)
   int auto_first = -1;         // first day of the last chain_run that ran in the child (-1: none)
   int auto_hint = -1;          // the same, relative to `first`, remembered for the next run
   long long auto_runs = 0;
@@ -1004,6 +1007,10 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
     ps_solver_destroy(s->child);
     s->child = nullptr;
   }
+  if (s->wide) {
+    ps_solver_destroy(s->wide);
+    s->wide = nullptr;
+  }
   if (s->borrowed) {   // stream and chain records are the parent's
     s->stream = nullptr;
     for (auto& p : s->recs[PS_REC_CHAIN]) p = nullptr;
@@ -1045,7 +1052,12 @@ extern "C" int ps_solver_retarget(ps_solver* s, int max_shape) {
       ps_solver_destroy(s->child);
       s->child = nullptr;
     }
+    if (s->wide) {   // a fast-mode solver cannot move its torus: rebuilt on demand
+      ps_solver_destroy(s->wide);
+      s->wide = nullptr;
+    }
     s->child_kernels = false;
+    s->wide_kernels = false;
     s->M = m;
     s->Pref = s->N + m;
     s->have_state = false;
@@ -1286,6 +1298,7 @@ static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const in
   s->bhat_count = 0;
   s->kernels_on_device = true;
   s->child_kernels = false;
+  s->wide_kernels = false;
   return PS_OK;
 }
 
@@ -1325,47 +1338,165 @@ int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, cons
   return set_kernels_common(s, nk, off, kshape, nullptr);
 }
 
-// PS_MODE_AUTO: days [f, end) continue in the fold-mode child from the field the chain had
-// before day f (record f-1, or the first-day state), on this solver's stream and into this
-// solver's records.  Whatever the front enqueued for days >= f is overwritten in stream order.
-static int auto_handover(ps_solver* s, int first, int f, int end, double negval, double stat_scale, int renorm) {
-  if (!s->child) {
+// ---- PS_MODE_AUTO beyond the clean prefix ----------------------------------------------------
+// From the first unclean day on, the days of the run alternate between two helpers that share
+// this solver's stream, kernels and records:
+//   * the WIDE solver: a fast-torus solver sized for N + 2M (not N + M).  A day that starts from a
+//     domain-supported state (after a flag's truncation, or a clean day) is a true LINEAR
+//     convolution there: its domain part is exactly the reference's, and with m' = the largest
+//     value outside the domain (overhangs do not overlap on this torus) the reference's flag --
+//     the maximum over its pad, where up to four overhang pieces are summed -- is certainly
+//     raised when m' > 1e-8 (pieces are non-negative) and certainly not when m' < 0.25e-8.  So
+//     the wide solver keeps the days with m' > 1e-8 (flagged: truncate + re-FFT on the device, as
+//     in fast mode) and the clean ones (m' < 1e-15);
+//   * the fold CHILD (PS_MODE_FOLD: the reference torus itself, pad dust included) takes every
+//     other day -- dust between 1e-15 and 1e-8 that the reference carries around its torus --
+//     starting from the field before that day, until one of its days raises the flag: the
+//     truncated field is domain-supported again and the wide solver resumes.
+// Days run in windows of 4; the window's pad maxima are read back and the first day that
+// belongs to the other helper restarts there (what was enqueued behind it is overwritten in
+// stream order).  `owner[d]` remembers which solver holds day d's statistics.
+static int auto_attach(ps_solver* s, ps_solver** slot, int mode, int max_shape, bool* kernels_ok, int end) {
+  if (!*slot) {
     ps_solver* c = nullptr;
-    PS_TRY(ps_solver_create(&c, s->device, s->N, 2 * s->M + 1, PS_MODE_FOLD));
+    PS_TRY(ps_solver_create(&c, s->device, s->N, max_shape, mode));
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
     c->stream = s->stream;
     c->borrowed = true;
-    s->child = c;
-    s->child_kernels = false;
+    c->speculate = false;                 // predicated re-FFT: the window logic here does the host checks
+    c->pad_floor = 0.5 * kCleanEps;
+    *slot = c;
+    *kernels_ok = false;
   }
-  ps_solver* c = s->child;
-  if (!s->child_kernels) {
+  ps_solver* c = *slot;
+  if (!*kernels_ok) {
     PS_TRY(ps_chain_adopt_device_kernels(c, s->nk, s->koff.data(), s->kshape.data(), s->krow.p, s->kcol.p, s->kval.p));
-    // the front may know tighter live-row ranges (host COO rows) than the whole K_d box
+    // the front may know tighter live-row ranges (host COO rows) than the whole K_d box; they are
+    // relative to the Kmax x Kmax staging block, which is the same in every helper
     c->hkrange = s->hkrange;
     PS_HIP(hipMemcpyAsync(c->krange.p, c->hkrange.data(), c->hkrange.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     PS_HIP(hipStreamSynchronize(c->stream));
-    s->child_kernels = true;
+    *kernels_ok = true;
   }
-  const double* prev = nullptr;
-  if (f > 0 && f - 1 < (int)s->recs[PS_REC_CHAIN].size() && s->recs[PS_REC_CHAIN][f - 1] && (f > first || first > 0))
-    prev = s->recs[PS_REC_CHAIN][f - 1];
-  else if (f == first && first == 0 && !s->recs[PS_REC_STATE].empty())
-    prev = s->recs[PS_REC_STATE][0];
-  if (!prev) return ps_fail(PS_ERR_STATE, "auto mode: no field to continue day %d from", f);
-  PS_TRY(c->torus.ensure((size_t)c->Pref * c->Pref));
-  PS_HIP(hipMemsetAsync(c->torus.p, 0, (size_t)c->Pref * c->Pref * sizeof(double), c->stream));
-  PS_HIP(hipMemcpy2DAsync(c->torus.p, (size_t)c->Pref * sizeof(double), prev, (size_t)s->N * sizeof(double),
-                          (size_t)s->N * sizeof(double), (size_t)s->N, hipMemcpyDeviceToDevice, c->stream));
-  c->have_state = true;
+  // statistics slots for the whole run up front: growing them later would drop the windows
+  // already computed (ensure_stats)
+  PS_TRY(ensure_stats(c, std::max(4, end)));
+  return PS_OK;
+}
+
+// the field the chain had before day d: record d-1, or the first-day state
+static const double* auto_prev_field(ps_solver* s, int first, int d) {
+  if (d > 0 && d - 1 < (int)s->recs[PS_REC_CHAIN].size() && s->recs[PS_REC_CHAIN][d - 1] && (d > first || first > 0))
+    return s->recs[PS_REC_CHAIN][d - 1];
+  if (d == first && first == 0 && !s->recs[PS_REC_STATE].empty()) return s->recs[PS_REC_STATE][0];
+  return nullptr;
+}
+
+static int auto_alias_records(ps_solver* s, ps_solver* c, int lo, int hi) {
   auto& cr = c->recs[PS_REC_CHAIN];
-  if ((int)cr.size() < end) cr.resize(end, nullptr);
-  for (int d = f; d < end; ++d) {
+  if ((int)cr.size() < hi) cr.resize(hi, nullptr);
+  for (int d = lo; d < hi; ++d) {
     PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
     cr[d] = s->recs[PS_REC_CHAIN][d];
   }
-  PS_TRY(ps_chain_run(c, f, end - f, negval, stat_scale, renorm));
+  return PS_OK;
+}
+
+static int auto_read_padmax(ps_solver* s, ps_solver* c, int d, int w, double* out) {
+  if (s->hflags_n < d + w) {
+    if (s->hflags) (void)hipHostFree(s->hflags);
+    s->hflags = nullptr;
+    s->hflags_n = 0;
+    PS_HIP(hipHostMalloc((void**)&s->hflags, (size_t)(d + w + 64) * sizeof(unsigned long long), hipHostMallocDefault));
+    s->hflags_n = d + w + 64;
+  }
+  PS_HIP(hipMemcpyAsync(s->hflags + d, c->padmax.p + d, (size_t)w * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  for (int i = 0; i < w; ++i) __builtin_memcpy(&out[i], &s->hflags[d + i], sizeof(double));
+  return PS_OK;
+}
+
+// `m_front`: what the front saw outside the domain on day f (its torus superposes the overhangs,
+// so the wide solver's m' is not larger): <= 1e-8 means day f cannot be a flagged day there --
+// start with the child.
+static int auto_handover(ps_solver* s, int first, int f, int end, double negval, double stat_scale, int renorm,
+                         double m_front) {
+  // The wide helper pays off where a day step is long against a host round trip per window and
+  // a solver per kernel-shape class is not rebuilt all the time: big grids (Carnarvon R = 2048
+  // rad_dist 10 km: 495 -> 570 grid-days/s; the R = 400 sampler, whose kernel extent moves with
+  // every proposal, ran 2x SLOWER with it).  PS_WIDE_MIN_N: smallest domain that uses it.
+  const int wide_min_n = getenv("PS_WIDE_MIN_N") ? atoi(getenv("PS_WIDE_MIN_N")) : 1500;   // read per call: tests switch it
+  const bool no_wide = getenv("PS_NO_WIDE") != nullptr || s->N < wide_min_n;   // fold child for everything
+  static const int kWin = getenv("PS_AUTO_WINDOW") ? std::min(64, std::max(1, atoi(getenv("PS_AUTO_WINDOW")))) : 4;
+  if ((int)s->owner.size() < end) s->owner.resize(end, 0);
+  for (int d = first; d < f; ++d) s->owner[d] = 0;
+  enum { WIDE = 1, CHILD = 2 };
+  int regime = (no_wide || !(m_front > 1e-8)) ? CHILD : WIDE;
+  s->auto_first_regime = regime;
+  bool wide_live = false, child_live = false;   // the helper's state continues the chain at day d
+  int d = f;
+  while (d < end) {
+    const double* prev = auto_prev_field(s, first, d);
+    if (regime == WIDE) {
+      PS_TRY(auto_attach(s, &s->wide, PS_MODE_FAST, 4 * s->M + 1, &s->wide_kernels, end));
+      ps_solver* c = s->wide;
+      if (!wide_live) {
+        if (!prev) return ps_fail(PS_ERR_STATE, "auto mode: no field to continue day %d from", d);
+        PS_TRY(ensure_record(c, PS_REC_STATE, 0));
+        PS_HIP(hipMemcpyAsync(c->recs[PS_REC_STATE][0], prev, (size_t)s->N * s->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        c->spec_valid = false;
+        c->have_state = true;
+        wide_live = true;
+        child_live = false;
+      }
+      const int w = std::min(kWin, end - d);
+      PS_TRY(auto_alias_records(s, c, d, d + w));
+      PS_TRY(ps_chain_run(c, d, w, negval, stat_scale, renorm));
+      double m[64];
+      PS_TRY(auto_read_padmax(s, c, d, std::min(w, 64), m));
+      int x = -1;
+      for (int i = 0; i < w && x < 0; ++i)
+        if (m[i] >= kCleanEps && !(m[i] > 1e-8)) x = d + i;     // dust the reference would carry: not ours
+      const int keep = x < 0 ? d + w : x;
+      for (int q = d; q < keep; ++q) s->owner[q] = WIDE;
+      d = keep;
+      if (x >= 0) {
+        regime = CHILD;
+        wide_live = false;
+      }
+    } else {
+      PS_TRY(auto_attach(s, &s->child, PS_MODE_FOLD, 2 * s->M + 1, &s->child_kernels, end));
+      ps_solver* c = s->child;
+      if (!child_live) {
+        if (!prev) return ps_fail(PS_ERR_STATE, "auto mode: no field to continue day %d from", d);
+        PS_TRY(c->torus.ensure((size_t)c->Pref * c->Pref));
+        PS_HIP(hipMemsetAsync(c->torus.p, 0, (size_t)c->Pref * c->Pref * sizeof(double), c->stream));
+        PS_HIP(hipMemcpy2DAsync(c->torus.p, (size_t)c->Pref * sizeof(double), prev, (size_t)s->N * sizeof(double),
+                                (size_t)s->N * sizeof(double), (size_t)s->N, hipMemcpyDeviceToDevice, c->stream));
+        c->have_state = true;
+        child_live = true;
+        wide_live = false;
+      }
+      const int w = no_wide ? end - d : std::min(kWin, end - d);
+      PS_TRY(auto_alias_records(s, c, d, d + w));
+      PS_TRY(ps_chain_run(c, d, w, negval, stat_scale, renorm));
+      int g = -1;
+      if (!no_wide) {
+        double m[64];
+        PS_TRY(auto_read_padmax(s, c, d, std::min(w, 64), m));
+        for (int i = 0; i < w && g < 0; ++i)
+          if (m[i] > 1e-8) g = d + i;                             // flagged: truncated, domain-supported again
+      }
+      const int keep = g < 0 ? d + w : g + 1;
+      for (int q = d; q < keep; ++q) s->owner[q] = CHILD;
+      d = keep;
+      if (g >= 0) {
+        regime = WIDE;
+        child_live = false;
+      }
+    }
+  }
   s->auto_first = f;
   s->auto_hint = f - first;
   s->have_state = false;   // the front's spectrum is void now: per-call API needs a new state
@@ -1471,7 +1602,8 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     s->auto_first = -1;
     ++s->auto_runs;
     if (count > 0 && s->auto_hint == 0 && s->auto_runs % 16 != 0)
-      return auto_handover(s, first, first, first + count, negval, stat_scale, renorm);
+      return auto_handover(s, first, first, first + count, negval, stat_scale, renorm,
+                           s->auto_first_regime == 1 ? 1.0 : 0.0);   // start where the last run's hand-over started
     if (s->auto_hint > 0) hint_abs = first + s->auto_hint;
   }
   if (s->speculate) {
@@ -1574,7 +1706,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
       }
       if (f < 0) continue;
       q.clear();   // whatever was enqueued after day f is void; stream order keeps it harmless
-      if (s->auto_exact) return auto_handover(s, first, f, first + count, negval, stat_scale, renorm);
+      if (s->auto_exact) {
+        double mf;
+        __builtin_memcpy(&mf, &s->hflags[f], sizeof(double));
+        return auto_handover(s, first, f, first + count, negval, stat_scale, renorm, mf);
+      }
       PS_TRY(fwd2d(s, s->recs[PS_REC_CHAIN][f], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf),
                    s->Ahat.p, 1, nullptr));
       if (d - f - 1 > 0)
@@ -1589,15 +1725,25 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
 extern "C" int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out) {
   if (!s || !out || first < 0 || count < 0 || first + count > s->nstat) return ps_fail(PS_ERR_BAD_ARG, "chain_stats: bad range");
   PS_HIP(hipSetDevice(s->device));
-  if (s->auto_exact && s->child && s->auto_first >= 0 && first + count > s->auto_first) {
-    // days from auto_first on ran in the fold-mode child (same day indices)
-    const int split = std::max(first, s->auto_first);
-    if (split > first) {
-      PS_TRY(finalize_days(s, first, split - first, s->last_renorm));
-      PS_HIP(hipStreamSynchronize(s->stream));
-      PS_HIP(hipMemcpy(out, s->dstats.p + first, (size_t)(split - first) * sizeof(DayStats), hipMemcpyDeviceToHost));
+  if (s->auto_exact && s->auto_first >= 0 && first + count > s->auto_first) {
+    // runs of days by owner: this solver (clean prefix), the wide helper, the fold child
+    int d = first;
+    while (d < first + count) {
+      const int o = d < (int)s->owner.size() ? s->owner[d] : 0;
+      int e = d + 1;
+      while (e < first + count && (e < (int)s->owner.size() ? s->owner[e] : 0) == o) ++e;
+      ps_solver* c = o == 1 ? s->wide : (o == 2 ? s->child : s);
+      if (!c) return ps_fail(PS_ERR_STATE, "auto mode: day %d has no owner", d);
+      if (c == s) {
+        PS_TRY(finalize_days(s, d, e - d, s->last_renorm));
+        PS_HIP(hipStreamSynchronize(s->stream));
+        PS_HIP(hipMemcpy(out + (d - first), s->dstats.p + d, (size_t)(e - d) * sizeof(DayStats), hipMemcpyDeviceToHost));
+      } else {
+        PS_TRY(ps_chain_stats(c, d, e - d, out + (d - first)));
+      }
+      d = e;
     }
-    return ps_chain_stats(s->child, split, first + count - split, out + (split - first));
+    return PS_OK;
   }
   PS_TRY(finalize_days(s, first, count, s->last_renorm));
   PS_HIP(hipStreamSynchronize(s->stream));
@@ -1997,6 +2143,15 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
 extern "C" int ps_solver_kernels_direct(ps_solver* s) { return s && s->kt_direct ? 1 : 0; }
 
 extern "C" int ps_solver_pipeline(ps_solver* s) { return s && s->tpipe ? 1 : 0; }
+
+extern "C" int ps_solver_auto_route(ps_solver* s, int first, int count, int32_t* owner) {
+  if (!s || !owner || first < 0 || count < 0) return ps_fail(PS_ERR_BAD_ARG, "auto_route: bad arguments");
+  for (int i = 0; i < count; ++i) {
+    const int d = first + i;
+    owner[i] = (s->auto_exact && s->auto_first >= 0 && d >= s->auto_first && d < (int)s->owner.size()) ? s->owner[d] : 0;
+  }
+  return PS_OK;
+}
 
 extern "C" int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_fft) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");

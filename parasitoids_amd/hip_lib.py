@@ -292,6 +292,13 @@ class HipSolve():
         L.check(self._lib.ps_solver_auto_info(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def auto_route(self, first, count):
+        '''PS_MODE_AUTO: per chain day of the last run_chain, 0 = fast-torus front (clean prefix),
+        1 = wide fast-torus helper (flagged / clean days), 2 = fold child (dusty days)'''
+        out = np.zeros(count, dtype=np.int32)
+        L.check(self._lib.ps_solver_auto_route(self._h, int(first), int(count), L.p_i32(out)))
+        return out
+
     @property
     def kernels_direct(self):
         '''True when the last chunk of day kernels took the direct-sum first column sub-pass

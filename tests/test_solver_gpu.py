@@ -104,7 +104,12 @@ def test_get_solutions_chain(hip_lib, golden, R, mode):
         f, fold_fft = solver.auto_info()
         flags = [bool(v) for v in g[tag + '_flags'][:nd - 1]]
         if any(flags):
-            assert 0 <= f <= flags.index(True) and fold_fft >= N + 3 * (ms[0] // 2)
+            assert 0 <= f <= flags.index(True)
+            route = solver.auto_route(0, nd - 1)
+            assert np.all(route[:f] == 0) and np.all(route[f:] >= 1)
+            # flagged days past the prefix ran on the wide fast torus or (right after dusty days) in the fold child
+            if np.any(route == 2):
+                assert fold_fft >= N + 3 * (ms[0] // 2)
     tol = ATOL if exact else 5e-8             # fast mode: pad-region semantics differ
     pos = g[tag + '_pos']
     for n in range(nd - 1):
@@ -295,7 +300,10 @@ def test_auto_mode_routes(hip_lib):
             f, fold_fft = s.auto_info()
             if expect_fold:
                 assert 0 <= f <= [bool(v) for v in trace['flags']].index(True)
-                assert fold_fft >= N + 3 * (K // 2)
+                route = s.auto_route(0, nd)
+                assert np.all(route[:f] == 0) and np.all(route[f:] >= 1)
+                if np.any(route == 2):
+                    assert fold_fft >= N + 3 * (K // 2)
             else:
                 assert f == -1 and fold_fft == 0 and not any(trace['flags'])
             for d in range(nd):
@@ -354,3 +362,58 @@ def test_flag_speculation_is_exact_in_the_full_column_pipeline(hip_lib, monkeypa
         for d in range(nd):
             assert np.abs(runs[0][0][d] - trace['raw'][d]).max() < 5e-8
             assert bool(flags[d]) == bool(trace['flags'][d])
+
+
+def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
+    """PS_MODE_AUTO past the clean prefix: flagged and clean days on the wide fast torus
+    (N + 2M), dusty days in the fold child, hand-overs in both directions -- forced on for small
+    domains here (PS_WIDE_MIN_N=0; by default only domains >= 1500 use the wide helper).  G6 at
+    R = 200 (16 of 17 days flagged) and synthetic chains whose first flag comes early / late:
+    raw fields, flags and thresholded solutions against the oracle, and the route shows that
+    both helpers ran."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_WIDE_MIN_N', '0')
+    seen = set()
+    # --- G6, R = 200
+    g = golden('g6_solutions')
+    nd = int(g['r200_ndays'])
+    pmfs = [coo_from(g, 'r200_pmf%d' % i) for i in range(nd)]
+    ms = g['r200_max_shape']
+    N = 401
+    first = recentre(pmfs[0], 200)
+    trace, modelsol = {}, [first]
+    OC.get_solutions(modelsol, pmfs, list(range(nd)), nd, N, ms, trace=trace)
+    s = hip_lib.HipSolve(first, ms, mode='auto', chain_only=True)
+    for rep in range(2):                      # second run: the hint path starts where the first did
+        if rep:
+            s.set_state(first)
+        s.set_kernels(pmfs[1:])
+        s.run_chain(0, nd - 1, renorm=True)
+        st = s.chain_stats(0, nd - 1)
+        route = s.auto_route(0, nd - 1)
+        seen |= set(int(v) for v in route)
+        for n in range(nd - 1):
+            np.testing.assert_allclose(s.dense(0, n), trace['raw'][n], rtol=0, atol=ATOL)
+            assert bool(st[n].flag) == bool(g['r200_flags'][n])
+            sol = s.chain_solution(n, st[n])
+            assert abs(sol.tocsr() - modelsol[n + 1].tocsr()).max() < 1e-12
+    s.close()
+    # --- synthetic: mass starting next to the edge
+    R, K, nd = 150, 101, 12
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(3.0, 6.0), shift=4)
+    for start in (230, 262, 285):
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        ref, trace = [state], {}
+        OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, np.array([K, K]), trace=trace)
+        s = hip_lib.HipSolve(state, [K, K], mode='auto', chain_only=True)
+        s.set_kernels(kernels)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        seen |= set(int(v) for v in s.auto_route(0, nd))
+        for d in range(nd):
+            np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13)
+            assert bool(st[d].flag) == bool(trace['flags'][d]), (start, d)
+            assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
+        s.close()
+    assert seen >= {0, 1, 2}, seen        # clean prefix, wide helper and fold child all took days
