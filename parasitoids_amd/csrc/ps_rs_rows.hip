@@ -1,0 +1,85 @@
+// Instantiations and launchers of the register-resident row kernels (fft_rs_kernels.h), one
+// translation unit so that they compile in parallel with the rest of the library.
+#include "rs_cfg.h"
+#include "rs_launch.h"
+
+bool rs_lookup(int L, int* r2, int* r3) {
+#define X(A, B) if (L == 16 * A * B) { *r2 = A; *r3 = B; return true; }
+  PS_RS_SIZES(X)
+#undef X
+  return false;
+}
+
+int rs_next_size(int n) {
+  int best = 0;
+#define X(A, B) if (16 * A * B >= n && (best == 0 || 16 * A * B < best)) best = 16 * A * B;
+  PS_RS_SIZES(X)
+#undef X
+  return best;
+}
+
+bool rs_info(int r2, int r3, RsInfo* out) {
+#define X(A, B)                                                                       \
+  if (r2 == A && r3 == B) {                                                           \
+    using C = RsCfg<A, B>;                                                            \
+    *out = RsInfo{C::NP, C::S::NTHR, C::LDS, C::LDSC1, C::LDSC, C::CHAIN};            \
+    return true;                                                                      \
+  }
+  PS_RS_SIZES(X)
+#undef X
+  return false;
+}
+
+int rs_rows_set_attrs() {
+#define X(A, B)                                                                                              \
+  {                                                                                                          \
+    using C = RsCfg<A, B>;                                                                                   \
+    constexpr int np = C::NP;                                                                                \
+    if (C::LDS > 48 * 1024) {                                                                                \
+      auto ki = k_row_inv_rs<16, A, B, np>;                                                                  \
+      auto kf = k_row_fwd_rs<16, A, B, np>;                                                                  \
+      if (hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess) return -1; \
+      if (hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess) return -1; \
+    }                                                                                                        \
+  }
+  PS_RS_SIZES(X)
+#undef X
+  return 0;
+}
+
+static int grid_x(int npairs, int np, int tstride) {
+  int gx = (npairs + np - 1) / np;
+  if (tstride) {   // column-major side: the workgroups sharing a 128-byte line sit on one XCD
+    const int m = 8 * (np >= 4 ? 1 : 4 / np);
+    gx = (gx + m - 1) / m * m;
+  }
+  return gx;
+}
+
+int rs_launch_row_fwd(int r2, int r3, const RowFwdArgs& a, int npairs, int batch, hipStream_t st) {
+#define X(A, B)                                                                                              \
+  if (r2 == A && r3 == B) {                                                                                  \
+    using C = RsCfg<A, B>;                                                                                   \
+    constexpr int np = C::NP;                                                                                \
+    auto kern = k_row_fwd_rs<16, A, B, np>;                                                                  \
+    hipLaunchKernelGGL(kern, dim3(grid_x(npairs, np, a.tstride), batch), dim3(C::S::NTHR * np), C::LDS, st, a); \
+    return 1;                                                                                                \
+  }
+  PS_RS_SIZES(X)
+#undef X
+  return 0;
+}
+
+int rs_launch_row_inv(int r2, int r3, const RowInvArgs& a, int npairs, int batch, hipStream_t st) {
+#define X(A, B)                                                                                              \
+  if (r2 == A && r3 == B) {                                                                                  \
+    using C = RsCfg<A, B>;                                                                                   \
+    constexpr int np = C::NP;                                                                                \
+    auto kern = k_row_inv_rs<16, A, B, np>;                                                                  \
+    hipLaunchKernelGGL(kern, dim3(grid_x(npairs, np, a.tstride), batch), dim3(C::S::NTHR * np), C::LDS, st, a); \
+    return 1;                                                                                                \
+  }
+  PS_RS_SIZES(X)
+#undef X
+  return 0;
+}

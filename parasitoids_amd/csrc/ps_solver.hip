@@ -5,9 +5,8 @@
 
 #include "chain_kernels.h"
 #include "fft_kernels.h"
-#include "fft_rs_kernels.h"
-#include "fft_colfull_kernels.h"
-#include "fft_rs_sizes.h"
+#include "fft_colfull_kernels.h"   // ColFullArgs (the kernels are instantiated in ps_colfull.hip)
+#include "rs_launch.h"
 #include "ps_common.h"
 
 thread_local std::string ps_tls_error;
@@ -309,35 +308,7 @@ static int col_threads() {
   return 256;
 }
 
-// ---------------------------------------------- register-resident row kernels (fft_rs.h)
-template <int R2, int R3>
-struct RsCfg {
-  using S = Rs<16, R2, R3>;
-  static constexpr int W = S::NTHR / 64;
-  // row pairs per workgroup: up to 12 waves (3 per SIMD at the ~165 registers of a radix-18 stage)
-  static constexpr int NP = 12 / W < 1 ? 1 : (12 / W > 4 ? 4 : 12 / W);
-  static constexpr size_t LDS = RsInvLds<16, R2, R3>::bytes(NP);
-  // full-column pass: one column per workgroup; the state column is parked in LDS next to the
-  // exchange buffer when both fit (k_colfull CHAIN)
-  static constexpr size_t LDSC1 = RsInvLds<16, R2, R3>::bytes(1);
-  static constexpr bool CHAIN = LDSC1 + (size_t)S::L * sizeof(cplx) <= (size_t)160 * 1024;
-  static constexpr size_t LDSC = CHAIN ? LDSC1 + (size_t)S::L * sizeof(cplx) : LDSC1;
-};
-static bool rs_lookup(int L, int* r2, int* r3) {
-#define X(A, B) if (L == 16 * A * B) { *r2 = A; *r3 = B; return true; }
-  PS_RS_SIZES(X)
-#undef X
-  return false;
-}
-// smallest served size >= n, or 0
-static int rs_next_size(int n) {
-  int best = 0;
-#define X(A, B) if (16 * A * B >= n && (best == 0 || 16 * A * B < best)) best = 16 * A * B;
-  PS_RS_SIZES(X)
-#undef X
-  return best;
-}
-
+// register-resident kernel families: rs_launch.h (instantiated in ps_rs_rows.hip / ps_colfull.hip)
 static int set_lds_attr() {
   static bool done = false;
   if (done) return PS_OK;
@@ -355,26 +326,7 @@ static int set_lds_attr() {
                       PS_MULTI_K(1), PS_MULTI_K(2), PS_MULTI_K(4), PS_MULTI_K(8)};
 #undef PS_MULTI_K
   for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-#define X(A, B)                                                                                              \
-  {                                                                                                          \
-    using C = RsCfg<A, B>;                                                                                   \
-    constexpr int np = C::NP;                                                                                \
-    if (C::LDS > 48 * 1024) {                                                                                \
-      auto ki = k_row_inv_rs<16, A, B, np>;                                                                  \
-      auto kf = k_row_fwd_rs<16, A, B, np>;                                                                  \
-      PS_HIP(hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS)); \
-      PS_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS)); \
-    }                                                                                                        \
-    if (C::LDSC > 48 * 1024) {                                                                               \
-      const void* kc[5] = {(const void*)k_colfull_day<16, A, B>, (const void*)k_colfull<16, A, B, false, 1>, \
-                           (const void*)k_colfull<16, A, B, false, 2>, (const void*)k_colfull<16, A, B, false, 3>, \
-                           (const void*)k_colfull<16, A, B, C::CHAIN, 0>};                                   \
-      for (const void* kk : kc)                                                                              \
-        PS_HIP(hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDSC));           \
-    }                                                                                                        \
-  }
-  PS_RS_SIZES(X)
-#undef X
+  if (rs_rows_set_attrs() != 0 || rs_colfull_set_attrs() != 0) return ps_fail(PS_ERR_HIP, "hipFuncSetAttribute failed for a register-resident kernel");
   done = true;
   return PS_OK;
 }
@@ -401,17 +353,8 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, pred ? PS_PROF_REFFT : PS_PROF_ROW_FWD);
   if (s->rs_r2 != 0 && getenv("PS_NO_RS_FWD") == nullptr) {
-#define X(A, B)                                                                                              \
-    if (s->rs_r2 == A && s->rs_r3 == B) {                                                                    \
-      using C = RsCfg<A, B>;                                                                                 \
-      constexpr int np = C::NP;                                                                              \
-      auto kern = k_row_fwd_rs<16, A, B, np>;                                                                \
-      int gx = (npairs + np - 1) / np;                                                                       \
-      if (a.tstride) { const int m = 8 * (np >= 4 ? 1 : 4 / np); gx = (gx + m - 1) / m * m; }               \
-      hipLaunchKernelGGL(kern, dim3(gx, batch), dim3(C::S::NTHR * np), C::LDS, s->stream, a);                 \
-    }
-    PS_RS_SIZES(X)
-#undef X
+    if (!rs_launch_row_fwd(s->rs_r2, s->rs_r3, a, npairs, batch, s->stream))
+      return ps_fail(PS_ERR_STATE, "no register-resident row kernel for 16 x %d x %d", s->rs_r2, s->rs_r3);
   } else if (s->row_plan.generic)
     hipLaunchKernelGGL((k_row_fwd<true, false>), grid, dim3(thr), lds, s->stream, a);
   else if (s->row_big)
@@ -494,17 +437,8 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, PS_PROF_ROW_INV);
   if (s->rs_r2 != 0) {
-#define X(A, B)                                                                                              \
-    if (s->rs_r2 == A && s->rs_r3 == B) {                                                                    \
-      using C = RsCfg<A, B>;                                                                                 \
-      constexpr int np = C::NP;                                                                              \
-      auto kern = k_row_inv_rs<16, A, B, np>;                                                                \
-      int gx = (npairs + np - 1) / np;                                                                       \
-      if (a.tstride) { const int m = 8 * (np >= 4 ? 1 : 4 / np); gx = (gx + m - 1) / m * m; }               \
-      hipLaunchKernelGGL(kern, dim3(gx, batch), dim3(C::S::NTHR * np), C::LDS, s->stream, a);                 \
-    }
-    PS_RS_SIZES(X)
-#undef X
+    if (!rs_launch_row_inv(s->rs_r2, s->rs_r3, a, npairs, batch, s->stream))
+      return ps_fail(PS_ERR_STATE, "no register-resident row kernel for 16 x %d x %d", s->rs_r2, s->rs_r3);
   } else if (s->row_plan.generic)
     hipLaunchKernelGGL((k_row_inv<true, false>), grid, dim3(thr), lds, s->stream, a);
   else if (s->row_big)
@@ -531,40 +465,23 @@ static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, 
   a.live = live;
   a.pred = pred;
   a.prog = s->row_plan.prog;
-  // see k_colfull: columns are handed out in groups of 8 x 8 XCDs
-  const int groups = (s->H + 7) / 8;
-  dim3 grid((unsigned)(((groups + 7) / 8) * 64), batch);
+  const int groups = (s->H + 7) / 8;       // 128-byte lines of the row-major output
+  const int lines8 = (groups + 7) / 8;     // per XCD
   ProfScope prof(s, pred ? PS_PROF_REFFT
                           : (mode == 1 ? PS_PROF_COL_FWD_A
                                        : (nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4
                                           : nd == 8 ? PS_PROF_COL_INV_A8 : PS_PROF_COL_INV_A)));
-#define X(A, B)                                                                                        \
-  if (s->rs_r2 == A && s->rs_r3 == B) {                                                                \
-    using C = RsCfg<A, B>;                                                                             \
-    if (nd > 1 && !C::CHAIN) return ps_fail(PS_ERR_UNSUPPORTED, "full-column pass: no room to chain days"); \
-    /* single passes take the state straight from HBM (162 registers, 255 us per day at 5184); only a  \
-       group of chained days parks it in LDS (246 registers: 294 us for one day, 218 per day for eight) */ \
-    auto k0 = k_colfull_day<16, A, B>;                                                                 \
-    auto k1 = k_colfull<16, A, B, false, 1>;                                                           \
-    auto k2 = k_colfull<16, A, B, false, 2>;                                                           \
-    auto k3 = k_colfull<16, A, B, false, 3>;                                                           \
-    auto kc = k_colfull<16, A, B, C::CHAIN, 0>;                                                        \
-    const bool chained = mode == 0 && nd > 1;                                                          \
-    auto kern = chained ? kc : (mode == 0 ? k0 : mode == 1 ? k1 : mode == 2 ? k2 : k3);                \
-    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), chained ? C::LDSC : C::LDSC1, s->stream, a);       \
-  }
-  PS_RS_SIZES(X)
-#undef X
+  if (!rs_launch_colfull(s->rs_r2, s->rs_r3, a, lines8, batch, s->stream))
+    return ps_fail(PS_ERR_UNSUPPORTED, "full-column pass: size 16 x %d x %d cannot run this (chained days need the state column in LDS)",
+                   s->rs_r2, s->rs_r3);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
 
 // can the full-column pass of this size chain days (state column parked in LDS)?
 static bool colfull_chains(const ps_solver* s) {
-#define X(A, B) if (s->rs_r2 == A && s->rs_r3 == B) return RsCfg<A, B>::CHAIN;
-  PS_RS_SIZES(X)
-#undef X
-  return false;
+  RsInfo info;
+  return rs_info(s->rs_r2, s->rs_r3, &info) && info.chain;
 }
 
 static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_ld, SrcMap rmap,

@@ -25,7 +25,7 @@ def pytest_configure(config):
     lib = os.path.join(ROOT, 'parasitoids_amd', 'libparasitoid_hip.so')
     if not os.path.exists(lib):
         import subprocess
-        subprocess.run(['make', '-C', os.path.join(ROOT, 'parasitoids_amd', 'csrc')], check=False)
+        subprocess.run(['make', '-j4', '-C', os.path.join(ROOT, 'parasitoids_amd', 'csrc')], check=False)
 
 
 @pytest.fixture(scope='session')
