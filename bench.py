@@ -40,12 +40,18 @@ MODEL_P2 = {
     'row_fwd': 16.0, 'col_fwd_a': 8.0, 'col_fwd_b': 8.0, 'col_inv_a': 40.0, 'col_inv_b': 8.0,
     'row_inv': 24.0, 'refft_pred': 0.0,
     'col_inv_a_x2': 80.0, 'col_inv_a_x4': 160.0, 'col_inv_a_x8': 320.0,
+    'row_inv_x2': 48.0, 'row_inv_x4': 96.0, 'row_inv_x8': 192.0,
 }
-DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8}
-# kernel class -> kernel symbol in the rocprofv3 PMC summaries under profiles/
-PMC_NAME = {'row_inv': 'void k_row_inv', 'col_inv_a': ('void k_col_fused<', 'void k_colfull_day<'), 'col_inv_b': 'void k_col<1',
-            'col_inv_a_x2': 'void k_col_fused_multi<false, 2,', 'col_inv_a_x4': 'void k_col_fused_multi<false, 4,',
-            'col_inv_a_x8': 'void k_col_fused_multi<false, 8,'}
+DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8,
+                   'row_inv_x2': 2, 'row_inv_x4': 4, 'row_inv_x8': 8}
+# kernel class -> (kernel symbol prefixes in the rocprofv3 PMC summaries under profiles/, days per
+# launch or None).  The multi-day launches of the full-column pipeline are ONE kernel each; the
+# summaries tell them apart by the LDS size of the dispatch (scripts/hbm_traffic.py: lds_rank).
+PMC_NAME = {'row_inv': (('void k_row_inv',), None), 'col_inv_b': (('void k_col<1',), None),
+            'col_inv_a': (('void k_col_fused<', 'void k_colfull_day<'), None)}
+for _n in (2, 4, 8):
+    PMC_NAME['col_inv_a_x%d' % _n] = (('void k_col_fused_multi<false, %d,' % _n, 'void k_colfull<'), _n)
+    PMC_NAME['row_inv_x%d' % _n] = (('void k_row_inv_rsp<',), _n)
 
 
 def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0):
@@ -61,7 +67,9 @@ def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0):
         # state in, state out, nd first-inverse-sub-pass outputs; the kernels' side is either
         # their live row-pass rows (direct sum / full-column pipeline) or nd intermediate spectra
         return (2 + nd) * S + (kernel_rows_bytes * nd if direct else nd * S)
-    return {'row_inv': S + F, 'col_inv_b': 2 * S, 'col_fwd_a': 2 * S, 'col_fwd_b': 2 * S,
+    if cls.startswith('row_inv'):
+        return nd * (S + F)
+    return {'col_inv_b': 2 * S, 'col_fwd_a': 2 * S, 'col_fwd_b': 2 * S,
             'row_fwd': None, 'refft_pred': None}.get(cls)
 
 
@@ -74,13 +82,19 @@ def pmc_traffic(kernel_class):
     import re
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_pmc.json')),
                    key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])   # r01_v10 after r01_v9
-    name = PMC_NAME.get(kernel_class)
-    if not files or name is None:
+    if not files or kernel_class not in PMC_NAME:
         return None, None
+    names, days = PMC_NAME[kernel_class]
     best = None
-    names = name if isinstance(name, tuple) else (name,)
     for e in json.load(open(files[-1])):
-        if e['kernel'].startswith(names) and (best is None or e['dispatches'] > best['dispatches']):
+        if not e['kernel'].startswith(names) or e.get('write_size_MB') is None:
+            continue
+        if days is not None and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
+            # groups of this kernel by LDS size are its 2-, 4-, 8-day launches in that order; a
+            # summary that does not hold all three cannot be attributed
+            if e.get('lds_groups') != 3 or e.get('lds_rank') != (2, 4, 8).index(days):
+                continue
+        if best is None or e['dispatches'] > best['dispatches']:
             best = e
     if best is None:
         return None, None
@@ -308,7 +322,7 @@ def main():
                 model_p2[k] += 8.0 * n
             model_p2['col_inv_a'] += 8.0
         fl = solver.fft_len
-        krows = solver.kernel_rows_bytes if hasattr(solver, 'kernel_rows_bytes') else 0.0
+        krows = K * (fl // 2 + 1) * 16.0   # the K row-pass rows of one day kernel (half spectra)
         for k, (ms, cnt) in prof.items():
             if cnt:
                 avg = ms / cnt

@@ -187,8 +187,9 @@ int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx
  * classes: 0 row_fwd, 1 col_fwd (first/single pass), 2 col_fwd (second sub-pass),
  * 3 col_inv (first pass, fused spectral product), 4 col_inv (second), 5 row_inv+epilogue,
  * 6 the three predicated passes of the flag-conditional re-FFT (no-ops when the flag is clear),
- * 7/8/9 class 3 for 2/4/8 consecutive days in one launch */
-#define PS_PROF_NCLS 10
+ * 7/8/9 class 3 for 2/4/8 consecutive days in one launch,
+ * 10/11/12 class 5 for the 2/4/8 days of a chained group in one launch (full-column pipeline) */
+#define PS_PROF_NCLS 13
 int ps_prof_enable(ps_solver* s, int on);   /* 0 off, 1 every launch, n > 1 every n-th launch per class */
 int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* count); /* synchronises */
 

@@ -164,8 +164,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
   cplx* sst = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);   // CHAIN: the state column, [L]
   const int j = threadIdx.x;
   const FftProg& P = a.prog;
-  const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
-  const cplx w3 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
+  const cplx w2c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
+  const cplx w3c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
   cplx* st = a.state + (int64_t)blockIdx.y * a.state_bstride + (int64_t)c * L;
   if constexpr (MODE == 2) {           // inverse of the state itself
     cplx x[S::RMAX];
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
       for (int q = 0; q < R1; ++q) x[q] = st[j + q * S::T1];
       bfly<R1, PS_INV>(x);
     }
-    rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
+    rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2c, w3c);
     if (j < S::T3) {
       cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (a.dst_t ? (int64_t)c * L : (int64_t)c);
       const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
       }
       bfly<R1, PS_FWD>(x);
     }
-    rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);
+    rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2c, w3c);
     if (j < S::T3) {
 #pragma unroll
       for (int q = 0; q < R3; ++q) st[j + q * S::T3] = x[q];
@@ -205,20 +205,38 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
       for (int q = 0; q < R3; ++q) sst[j + q * S::T3] = st[j + q * S::T3];
     }
     const int nd = (CHAIN && MODE == 0) ? a.nd : 1;
+    // CHAIN: the kernel column of the NEXT day is fetched into xn while this day's inverse
+    // transform runs (64 registers; the loop body needs 128).  Without it the fetch waits behind
+    // the previous day's 66 KB of output stores in the CU's memory pipeline and nothing else can
+    // run meanwhile (one workgroup per CU): 52 of 221 us per day at 5184, another 50 for the stores.
+    cplx xn[R1];
+    auto fetch = [&](int day, int jt) {
+      const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)day * a.src_dstride + (int64_t)c * L;
+      if (jt < S::T1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+          const int n = jt + q * S::T1;
+          xn[q] = make_double2(0.0, 0.0);
+          if (row_live(a.live, n, (int)blockIdx.y + day)) xn[q] = sc[n];
+        }
+      }
+    };
+    if (CHAIN && MODE == 0) fetch(0, j);
     for (int day = 0; day < nd; ++day) {
       cplx x[S::RMAX];
       // opaque copy of the thread index: keeps the compiler from hoisting the body's ~100
       // loop-invariant addresses out of the day loop (256 registers and scratch otherwise)
       int jv = threadIdx.x;
       asm volatile("" : "+v"(jv));
-      const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)day * a.src_dstride + (int64_t)c * L;
+      // ... and of the stage twiddles: their powers (rs_stage) are loop-invariant too, 40 complex
+      // values that would stay in registers across the whole loop (246 registers at 5184, scratch
+      // from 5376 up); recomputing them per transform costs ~20 complex products
+      cplx w2 = w2c, w3 = w3c;
+      asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(w3.x), "+v"(w3.y));
+      if (!(CHAIN && MODE == 0)) fetch(day, jv);
       if (jv < S::T1) {
 #pragma unroll
-        for (int q = 0; q < R1; ++q) {
-          const int n = jv + q * S::T1;
-          x[q] = make_double2(0.0, 0.0);
-          if (row_live(a.live, n, (int)blockIdx.y + day)) x[q] = sc[n];
-        }
+        for (int q = 0; q < R1; ++q) x[q] = xn[q];
         bfly<R1, PS_FWD>(x);
       }
       rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, jv, w2, w3);   // thread jv < T3: X[jv + q T3]
@@ -240,7 +258,18 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
           }
         }
       }
-      if constexpr (MODE == 0) {
+      if constexpr (MODE == 0 && CHAIN) {
+        // natural order (jv + q T3) -> first-stage input order (jv + q T1): the product was just
+        // parked in the LDS state column, which IS the inverse transform's input -- one barrier and
+        // 16-byte reads instead of a real/imaginary round trip through the exchange buffer
+        __syncthreads();
+        if (jv < S::T1) {
+#pragma unroll
+          for (int q = 0; q < R1; ++q) x[q] = sst[jv + q * S::T1];
+        }
+        if (day + 1 < nd) fetch(day + 1, jv);   // in flight during the inverse transform below
+      }
+      if constexpr (MODE == 0 && !CHAIN) {
         // natural order (jv + q T3) -> first-stage input order (jv + q T1), real parts then imaginary
         __syncthreads();
         if (jv < S::T3) {
@@ -263,6 +292,9 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
           for (int q = 0; q < R1; ++q) x[q].y = ex[jv + q * S::T1];
         }
         __syncthreads();
+      }
+      if constexpr (MODE == 0) {
+        if (CHAIN) asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(w3.x), "+v"(w3.y));
         if (jv < S::T1) bfly<R1, PS_INV>(x);
         rs_tail<S, R1, R2, R3, PS_INV>(x, ex, jv, w2, w3);     // thread jv < T3: spatial rows jv + q T3
         if (jv < S::T3) {

@@ -102,6 +102,11 @@ struct RowInvArgs {
   unsigned long long* padmax; // bits of max(pad, 0)
   double pad_floor;           // pad maxima at or below this are not published (0.5e-8: only what can raise the flag)
   int64_t stat_bstride;       // per-batch stride of rowsum/rowcnt (padmax: 1)
+  // k_row_inv_rsp (persistent, prefetching; register-resident sizes up to 6400): chosen by the
+  // launcher when the input does not come straight out of the Infinity Cache (full-column pipeline)
+  int persistent;
+  int nrec;                   // > 0: batch entry b writes rec_multi[b] (the days of a chained group)
+  double* rec_multi[8];
   FftProg prog;
 };
 

@@ -90,25 +90,38 @@ PS_HD void rs_stage(cplx* x, cplx w1, bool tw) {
 }
 
 #if defined(__HIPCC__)
+// Workgroup barrier for the LDS exchanges WITHOUT the memory-model fence of __syncthreads(): the
+// fence makes the compiler wait for every outstanding vector-memory operation, which would drain
+// the asynchronous HBM -> LDS prefetch of the persistent kernels (k_row_inv_rsp) at the first
+// exchange.  LDS traffic of this wave is complete (lgkmcnt 0) before the barrier, which is all the
+// exchanges need.
+#define PS_BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PS_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+template <bool RAW>
+__device__ __forceinline__ void rs_bar() {
+  if (RAW) PS_BAR_LDS();
+  else __syncthreads();
+}
+
 // stages 2 and 3 with both exchanges; on entry x holds the stage-1 OUTPUT of thread j,
 // on exit the stage-3 output (natural index j + q' T3) of thread j < T3.
-template <class S, int R1, int R2, int R3, int DIR>
+template <class S, int R1, int R2, int R3, int DIR, bool RAW = false>
 __device__ __forceinline__ void rs_tail(cplx* x, double* ex, const int j, const cplx w2, const cplx w3) {
   if (j < S::T1) rs_put<R1, 0>(ex, S::x1_w(j), 1, x);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T2) rs_get<R2, 0>(ex, S::x_r(j), S::X1_RS, x);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T1) rs_put<R1, 1>(ex, S::x1_w(j), 1, x);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T2) rs_get<R2, 1>(ex, S::x_r(j), S::X1_RS, x);
   if (j < S::T2) rs_stage<R2, DIR>(x, w2, true);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T2) rs_put<R2, 0>(ex, S::x2_w(j), 17, x);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T3) rs_get<R3, 0>(ex, S::x_r(j), S::X2_RS, x);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T2) rs_put<R2, 1>(ex, S::x2_w(j), 17, x);
-  __syncthreads();
+  rs_bar<RAW>();
   if (j < S::T3) rs_get<R3, 1>(ex, S::x_r(j), S::X2_RS, x);
   if (j < S::T3) rs_stage<R3, DIR>(x, w3, true);
 }

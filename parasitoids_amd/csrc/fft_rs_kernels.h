@@ -183,6 +183,197 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
 }
 
 
+// ------------------------------------------------------------ inverse rows, persistent + prefetch
+// Same transform and epilogue as k_row_inv_rs, organised for ONE workgroup per CU that walks its
+// share of the row pairs.  What k_row_inv_rs cannot do with one resident workgroup -- fetch the
+// next rows while this pair is being transformed -- is done by the load unit itself: the two
+// half-spectrum rows of the NEXT pair are copied HBM -> LDS by global_load_lds_dwordx4 (no
+// registers, no waiting wave) while the three stages and both exchanges of the current pair run,
+// and the first stage then takes its Hermitian-extended inputs from LDS.  It also shrinks the
+// scheduling quantum from a workgroup of two pairs to one pair: the 2049 domain pairs of the
+// 4097^2 stack are 8.004 rounds of 256 CUs, which cost 5 rounds of two-pair workgroups (4.002
+// needed) but 9 of these half-length ones.
+// LDS: exchange buffer (L * 8.5 B) + two staged rows (2 * (L/2 + 1) * 16 B) = 24.5 L bytes, so
+// sizes up to L = 6400 (5184: 128 KB); larger ones keep k_row_inv_rs.  Row-major input only: gathering
+// a column-major intermediate (PS_TINV) 16 bytes per line costs the load unit 122 us more per day
+// than the contiguous stores save the column pass (25 us), asynchronous or not.
+typedef __attribute__((address_space(3))) void* ps_lds_ptr;
+
+template <int R1, int R2, int R3>
+struct RsPLds {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  static constexpr int HS = (S::L / 2 + 1 + 63) & ~63;   // a staged row: whole 64-element chunks
+  static constexpr size_t bytes = (size_t)(Y::XW + Y::RED) * sizeof(double) + 2 * (size_t)HS * sizeof(cplx);
+  static constexpr bool fits = bytes + 3 * 2048 <= (size_t)160 * 1024;   // + the launch tag (PS_LDS_TAG, rs_cfg.h)
+};
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvArgs a, int npairs, int units) {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  using Z = RsPLds<R1, R2, R3>;
+  constexpr int L = S::L;
+  constexpr int NW = S::NTHR / 64;
+  constexpr int NCH = Z::HS / 64;              // 1 KB chunks per staged row
+  constexpr int H = L / 2 + 1;
+  double* ex = reinterpret_cast<double*>(ps_lds_raw);
+  double* red = ex + Y::XW;      // 5 * NW doubles
+  cplx* stA = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);
+  cplx* stB = stA + Z::HS;
+  const int j0 = threadIdx.x, lane = j0 & 63, wave = j0 >> 6;
+  const FftProg& P = a.prog;
+  const cplx w2c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j0));
+  const cplx w3c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j0 < S::T3 ? S::tw3(j0) : 0);
+
+  // rows of unit u -> staging; every wave copies the chunks c = wave, wave + NW, ... (row A, then B)
+  auto prefetch = [&](int u) {
+    const int b = u / npairs, pair = u - b * npairs;
+    const cplx* src = a.src + (int64_t)b * a.src_bstride;
+    const int ra = 2 * pair, rb = (ra + 1 < a.P) ? ra + 1 : ra;
+    const cplx* pa = src + (int64_t)ra * a.ld;
+    const cplx* pb = src + (int64_t)rb * a.ld;
+#pragma unroll
+    for (int t = 0; t < (2 * NCH + NW - 1) / NW; ++t) {
+      const int c = wave + t * NW;             // wave-uniform
+      if (c < 2 * NCH) {
+        const bool isb = c >= NCH;
+        const int cc = isb ? c - NCH : c;
+        int k = cc * 64 + lane;
+        k = k < H ? k : H - 1;                 // the last chunk: stay inside the row
+        const cplx* g = (isb ? pb : pa) + k;
+        cplx* d = (isb ? stB : stA) + cc * 64; // + lane * 16 B by the instruction
+        __builtin_amdgcn_global_load_lds(g, (ps_lds_ptr)d, 16, 0, 0);
+      }
+    }
+  };
+
+  int u = (int)blockIdx.x;
+  if (u < units) prefetch(u);
+  PS_WAIT_VM0();
+  for (; u < units; u += (int)gridDim.x) {
+    const int b = u / npairs, pair = u - b * npairs;
+    const int ra = 2 * pair, rb = ra + 1;
+    const bool hasb = rb < a.P;
+    const bool pad_only = ra >= a.N;
+    // opaque per-round copies: nothing derived from the thread index or the stage twiddles is
+    // loop-invariant for the compiler, which would otherwise hoist ~100 registers of twiddle
+    // powers and LDS addresses out of the loop (and spill)
+    int j = j0;
+    cplx w2 = w2c, w3 = w3c;
+    asm volatile("" : "+v"(j), "+v"(w2.x), "+v"(w2.y), "+v"(w3.x), "+v"(w3.y));
+    PS_BAR_LDS();                               // every wave's chunks of this unit have landed
+    cplx x[S::RMAX];
+    double energy = 0.0;
+    if (j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) {
+        const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);   // j + q T1 <= L/2
+        const int i = j + q * S::T1;
+        const int k = direct ? i : L - i;
+        const cplx A = stA[k];
+        cplx B = stB[k];
+        if (!hasb) B = make_double2(0.0, 0.0);
+        if (direct) energy += A.x * A.x + A.y * A.y + B.x * B.x + B.y * B.y;
+        x[q] = direct ? make_double2(A.x - B.y, A.y + B.x) : make_double2(A.x + B.y, B.x - A.y);
+      }
+    }
+    if (pad_only) {   // uniform per workgroup
+      for (int off = 32; off > 0; off >>= 1) energy += __shfl_down(energy, off);
+      if (lane == 0) red[wave] = energy;
+    }
+    PS_BAR_LDS();                               // staging is free again
+    if (u + (int)gridDim.x < units) prefetch(u + (int)gridDim.x);
+    if (pad_only) {
+      // Parseval bound on the largest value of a pad-only pair (see k_row_inv)
+      double e = 0.0;
+      for (int w = 0; w < NW; ++w) e += red[w];
+      if (sqrt(2.0 * (double)a.P * e) * a.scale < a.pad_floor) {
+        PS_WAIT_VM0();
+        continue;
+      }
+    }
+    if (j < S::T1) bfly<R1, PS_INV>(x);
+    rs_tail<S, R1, R2, R3, PS_INV, true>(x, ex, j, w2, w3);
+    // the prefetch has had the whole transform to land; waiting for it HERE (before this pair's
+    // stores are issued) keeps the stores out of the wait at the top of the next round
+    PS_WAIT_VM0();
+
+    double* rec = a.nrec > 0 ? a.rec_multi[b] : a.rec + (int64_t)b * a.rec_bstride;
+    double sa = 0.0, sb = 0.0, pmax = 0.0;
+    int ca = 0, cb = 0;
+    if (j < S::T3) {
+      double* reca = rec + (int64_t)ra * a.N;
+      double* recb = rec + (int64_t)rb * a.N;
+      const bool dom_a = ra < a.N, dom_b = rb < a.N;
+      const unsigned uj = (unsigned)j, uN = (unsigned)a.N;
+      const bool dom_ab = dom_a && dom_b;
+#pragma unroll
+      for (int q = 0; q < R3; ++q) {
+        const unsigned i = uj + (unsigned)(q * S::T3);
+        const double va = x[q].x * a.scale, vb = x[q].y * a.scale;
+        const double ta = va * a.stat_scale, tb = vb * a.stat_scale;
+        if (dom_ab && (unsigned)((q + 1) * S::T3) <= uN) {
+          reca[i] = va;
+          recb[i] = vb;
+          const bool ka = !(ta < a.negval), kb = !(tb < a.negval);
+          sa += ka ? ta : 0.0;
+          sb += kb ? tb : 0.0;
+          ca += ka ? 1 : 0;
+          cb += kb ? 1 : 0;
+        } else {
+          const bool in = i < uN;
+          const bool ina = in && dom_a, inb = in && dom_b;
+          const bool ka = ina && !(ta < a.negval), kb = inb && !(tb < a.negval);
+          sa += ka ? ta : 0.0;
+          sb += kb ? tb : 0.0;
+          ca += ka ? 1 : 0;
+          cb += kb ? 1 : 0;
+          pmax = fmax(pmax, ina ? 0.0 : va);
+          pmax = fmax(pmax, (inb || !hasb) ? 0.0 : vb);
+          if (ina) reca[i] = va;
+          if (inb) recb[i] = vb;
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      sa += __shfl_down(sa, off);
+      sb += __shfl_down(sb, off);
+      ca += __shfl_down(ca, off);
+      cb += __shfl_down(cb, off);
+      pmax = fmax(pmax, __shfl_down(pmax, off));
+    }
+    double* redm = red + 4 * NW;
+    if (lane == 0) {
+      red[wave * 4 + 0] = sa;
+      red[wave * 4 + 1] = sb;
+      red[wave * 4 + 2] = (double)ca;
+      red[wave * 4 + 3] = (double)cb;
+      redm[wave] = pmax;
+    }
+    PS_BAR_LDS();
+    if (j == 0) {
+      double ta = 0, tb = 0, na = 0, nbb = 0, m = 0;
+      for (int w = 0; w < NW; ++w) {
+        ta += red[w * 4 + 0];
+        tb += red[w * 4 + 1];
+        na += red[w * 4 + 2];
+        nbb += red[w * 4 + 3];
+        m = fmax(m, redm[w]);
+      }
+      double* rowsum = a.rowsum + (int64_t)b * a.stat_bstride;
+      long long* rowcnt = a.rowcnt + (int64_t)b * a.stat_bstride;
+      if (ra < a.N) { rowsum[ra] = ta; rowcnt[ra] = (long long)na; }
+      if (rb < a.N) { rowsum[rb] = tb; rowcnt[rb] = (long long)nbb; }
+      unsigned long long* pm = a.padmax + b;
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+      if (m > a.pad_floor && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(pm, bits);
+    }
+  }
+}
+
+
 // ------------------------------------------------------------ forward rows
 // Two real rows (ra, rb) -> z = a + i b, loaded by the first stage straight from the source
 // (zero outside the row/column maps) -> three register stages -> Z in natural order, thread j

@@ -2,6 +2,7 @@
 // translation unit so that they compile in parallel with the rest of the library.
 #include "rs_cfg.h"
 #include "rs_launch.h"
+#include <cstdlib>
 
 bool rs_lookup(int L, int* r2, int* r3) {
 #define X(A, B) if (L == 16 * A * B) { *r2 = A; *r3 = B; return true; }
@@ -22,7 +23,7 @@ bool rs_info(int r2, int r3, RsInfo* out) {
 #define X(A, B)                                                                       \
   if (r2 == A && r3 == B) {                                                           \
     using C = RsCfg<A, B>;                                                            \
-    *out = RsInfo{C::NP, C::S::NTHR, C::LDS, C::LDSC1, C::LDSC, C::CHAIN};            \
+    *out = RsInfo{C::NP, C::S::NTHR, C::LDS, C::LDSC1, C::LDSC, C::CHAIN, RsPLds<16, A, B>::fits};            \
     return true;                                                                      \
   }
   PS_RS_SIZES(X)
@@ -35,6 +36,11 @@ int rs_rows_set_attrs() {
   {                                                                                                          \
     using C = RsCfg<A, B>;                                                                                   \
     constexpr int np = C::NP;                                                                                \
+    using Z = RsPLds<16, A, B>;                                                                              \
+    if constexpr (Z::fits) {                                                                                 \
+      auto kp = k_row_inv_rsp<16, A, B>;                                                                     \
+      if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Z::bytes + 3 * PS_LDS_TAG)) != hipSuccess) return -1; \
+    }                                                                                                        \
     if (C::LDS > 48 * 1024) {                                                                                \
       auto ki = k_row_inv_rs<16, A, B, np>;                                                                  \
       auto kf = k_row_fwd_rs<16, A, B, np>;                                                                  \
@@ -70,10 +76,32 @@ int rs_launch_row_fwd(int r2, int r3, const RowFwdArgs& a, int npairs, int batch
   return 0;
 }
 
+// workgroups of the persistent kernel: one per CU
+static int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 int rs_launch_row_inv(int r2, int r3, const RowInvArgs& a, int npairs, int batch, hipStream_t st) {
 #define X(A, B)                                                                                              \
   if (r2 == A && r3 == B) {                                                                                  \
     using C = RsCfg<A, B>;                                                                                   \
+    using Z = RsPLds<16, A, B>;                                                                              \
+    if constexpr (Z::fits) {                                                                                 \
+      if (a.persistent && a.tstride == 0) {                                                                  \
+        const int units = npairs * batch;                                                                    \
+        const int wgs = units < device_cus() ? units : device_cus();                                         \
+        auto kp = k_row_inv_rsp<16, A, B>;                                                                   \
+        hipLaunchKernelGGL(kp, dim3(wgs), dim3(C::S::NTHR), Z::bytes + ps_lds_tag(a.nrec), st, a, npairs, units); \
+        return 1;                                                                                            \
+      }                                                                                                      \
+    }                                                                                                        \
     constexpr int np = C::NP;                                                                                \
     auto kern = k_row_inv_rs<16, A, B, np>;                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid_x(npairs, np, a.tstride), batch), dim3(C::S::NTHR * np), C::LDS, st, a); \

@@ -141,10 +141,11 @@ static const int kPredGrid = 512;  // grid of the flag-conditional (usually empt
 // (a convolution with a pmf cannot raise the maximum of the dust it moves), so the fast chain IS
 // the exact-torus chain to <= 4 * days * kCleanEps.  FFT round-off in the pad is ~1e-18.
 static const double kCleanEps = 1e-15;
-#define PS_PROF_NCLS 10
+#define PS_PROF_NCLS 13
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
        PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6, PS_PROF_COL_INV_A2 = 7,
-       PS_PROF_COL_INV_A4 = 8, PS_PROF_COL_INV_A8 = 9 };
+       PS_PROF_COL_INV_A4 = 8, PS_PROF_COL_INV_A8 = 9, PS_PROF_ROW_INV2 = 10, PS_PROF_ROW_INV4 = 11,
+       PS_PROF_ROW_INV8 = 12 };
 
 struct ColPass {
   DevPlan* plan;
@@ -407,9 +408,32 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   return PS_OK;
 }
 
+// the persistent row kernel serves this solver's size (and is not switched off)
+static bool row_inv_persistent(const ps_solver* s) {
+  static const int knob = getenv("PS_RSP") ? atoi(getenv("PS_RSP")) : -1;   // A/B knob: 0 never, 1 wherever it exists
+  RsInfo info;
+  if (s->rs_r2 == 0 || !rs_info(s->rs_r2, s->rs_r3, &info) || !info.rsp || knob == 0) return false;
+  // The tiled pipeline hands each day's spectrum over through the Infinity Cache (215 MB written by
+  // the column sub-pass just before): the one-shot kernel reads it at 108 us per day where this one
+  // needs 126.  The full-column pipeline writes whole groups of days first, the rows come from HBM,
+  // and the prefetch wins (127 against 144 us).
+  return knob == 1 || s->tpipe;
+}
+
+// `recs_multi` != nullptr: batch entry b writes recs_multi[b] (separately allocated day records;
+// needs row_inv_persistent(s) and batch <= 8)
 static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_slot, int batch,
-                          double negval, double stat_scale, bool full_field = false) {
+                          double negval, double stat_scale, bool full_field = false,
+                          double* const* recs_multi = nullptr) {
   RowInvArgs a;
+  a.persistent = (row_inv_persistent(s) && !(s->tpipe && s->tinv && !full_field)) ? 1 : 0;
+  a.nrec = 0;
+  for (int i = 0; i < 8; ++i) a.rec_multi[i] = nullptr;
+  if (recs_multi) {
+    if (!a.persistent || batch > 8) return ps_fail(PS_ERR_STATE, "row pass: a record table needs the persistent kernel and at most 8 entries");
+    a.nrec = batch;
+    for (int i = 0; i < batch; ++i) a.rec_multi[i] = recs_multi[i];
+  }
   a.src = src; a.src_bstride = (int64_t)s->Pf * s->ld;
   a.H = s->H; a.ld = s->ld; a.P = s->Pf; a.N = s->N;
   a.tstride = (s->tpipe && s->tinv && !full_field) ? s->Pf : 0;   // full-column pipeline: column-major intermediate
@@ -435,7 +459,8 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
-  ProfScope prof(s, PS_PROF_ROW_INV);
+  ProfScope prof(s, !recs_multi ? PS_PROF_ROW_INV : batch == 2 ? PS_PROF_ROW_INV2 : batch == 4 ? PS_PROF_ROW_INV4
+                                : batch == 8 ? PS_PROF_ROW_INV8 : PS_PROF_ROW_INV);
   if (s->rs_r2 != 0) {
     if (!rs_launch_row_inv(s->rs_r2, s->rs_r3, a, npairs, batch, s->stream))
       return ps_fail(PS_ERR_STATE, "no register-resident row kernel for 16 x %d x %d", s->rs_r2, s->rs_r3);
@@ -730,8 +755,14 @@ static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, dou
     RowLive live = s->kt_live;
     live.range = rowrange;
     PS_TRY(launch_colfull(s, 0, kt, state, 1, s->T1.p, 1, live, nullptr, nd));
-    for (int i = 0; i < nd; ++i)
-      PS_TRY(launch_row_inv(s, s->T1.p + i * spec, recs[i], d0 + i, 1, negval, stat_scale));
+    if (row_inv_persistent(s) && !s->tinv && nd <= 8 && getenv("PS_NO_ROW_BATCH") == nullptr) {
+      // one launch for the rows of all nd days: nd x 2593 units over 256 persistent workgroups leave
+      // 1/80 of a round idle at the end instead of 1/11 per day
+      PS_TRY(launch_row_inv(s, s->T1.p, nullptr, d0, nd, negval, stat_scale, false, recs));
+    } else {
+      for (int i = 0; i < nd; ++i)
+        PS_TRY(launch_row_inv(s, s->T1.p + i * spec, recs[i], d0 + i, 1, negval, stat_scale));
+    }
     *done = 1;
     return PS_OK;
   }
@@ -1542,7 +1573,12 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   if (s->tpipe_ok && !s->spec_valid) {
     bool compact = direct_possible(s);
     for (int d = first; d < first + count && compact; ++d) compact = day_is_compact(s, d);
-    bool want = !(s->split && compact);   // single-pass column sizes too: +6 % on the flag-heavy R = 400 Bayes chain
+    // Compact kernels on a split column size have the direct-sum tiled route (4-day groups, no kernel
+    // spectra in HBM); it still wins where the full-column pass cannot chain days (state column + exchange
+    // buffer beyond LDS, L > 6400).  Everywhere else the full-column pipeline is ahead since the
+    // persistent row kernel and the pipelined kernel fetch: 10.5 against 11.7 ms per 30-day stack at 5184,
+    // 8.2 against 9.4 at 4608 (single-pass column sizes too: +6 % on the flag-heavy R = 400 Bayes chain).
+    bool want = !(s->split && compact) || colfull_chains(s);
     if (const char* e = getenv("PS_TPIPE")) want = atoi(e) != 0;   // A/B knob
     set_pipeline(s, want);
   }

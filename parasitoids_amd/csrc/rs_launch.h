@@ -14,6 +14,7 @@ struct RsInfo {
   int np, nthr;
   size_t lds_rows, lds_col1, lds_colc;
   bool chain;
+  bool rsp;   // k_row_inv_rsp exists for this size (its staged rows fit in LDS)
 };
 bool rs_lookup(int L, int* r2, int* r3);
 int rs_next_size(int n);   // smallest served size >= n, or 0

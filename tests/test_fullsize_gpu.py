@@ -269,6 +269,7 @@ def test_direct_sum_subpass_matches_fft_subpass(hip_lib, monkeypatch):
     spans at and beyond the term limit (fallback), an empty day kernel, mixed shapes; fast
     mode (multi-day fused passes; single-day pass and re-FFT once flags fire); fold mode runs
     the same chains for reference (it never takes the direct route)."""
+    monkeypatch.setenv('PS_TPIPE', '0')   # the tiled pipeline is what this test is about
     R, K = 640, 801
     N, M = 2 * R + 1, K // 2
     rng = np.random.default_rng(77)
@@ -336,6 +337,7 @@ def test_multi_day_fused_pass_is_bit_identical(hip_lib, monkeypatch, R, K, mode)
     2, 4, 4 + 1).  The direct-sum route is switched off here: it changes round-off."""
     from parasitoids_amd import synthetic
     monkeypatch.setenv('PS_NO_DIRECT', '1')
+    monkeypatch.setenv('PS_TPIPE', '0')   # k_col_fused_multi belongs to the tiled pipeline
     nd = 11
     state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=3, sigma=(2.0, 6.0), shift=4.0)
     out = {}
