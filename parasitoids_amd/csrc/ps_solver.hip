@@ -410,7 +410,8 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
 
 // the persistent row kernel serves this solver's size (and is not switched off)
 static bool row_inv_persistent(const ps_solver* s) {
-  static const int knob = getenv("PS_RSP") ? atoi(getenv("PS_RSP")) : -1;   // A/B knob: 0 never, 1 wherever it exists
+  const char* e = getenv("PS_RSP");   // A/B knob: 0 never, 1 wherever it exists (read per launch: tests flip it)
+  const int knob = e ? atoi(e) : -1;
   RsInfo info;
   if (s->rs_r2 == 0 || !rs_info(s->rs_r2, s->rs_r3, &info) || !info.rsp || knob == 0) return false;
   // The tiled pipeline hands each day's spectrum over through the Infinity Cache (215 MB written by
@@ -937,7 +938,14 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e != hipSuccess) return fail(ps_fail(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
   const size_t spec = (size_t)s->Pf * s->ld;
-  const size_t budget = (size_t)3 << 30;  // bytes of batched kernel spectra per chunk
+  // bytes of batched kernel spectra per chunk: 1/16 of the device memory (18 GB of the MI355X's 288),
+  // so the 30 kernels of a 4097^2 stack (6.4 GB) are one chunk and the speculation windows keep
+  // growing (2, 4, 8, 8, 8 days) instead of starting over at every chunk boundary
+  size_t budget = (size_t)3 << 30;
+  {
+    size_t mfree = 0, mtotal = 0;
+    if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mtotal / 16 > budget) budget = mtotal / 16;
+  }
   s->chunk_days = (int)std::max<size_t>(1, std::min<size_t>(64, budget / (spec * sizeof(cplx))));
   if (const char* e = getenv("PS_CHUNK_DAYS")) s->chunk_days = std::max(1, atoi(e));   // tuning knob
   if ((rc = s->Ahat.ensure(spec))) return fail(rc);

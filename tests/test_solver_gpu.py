@@ -417,3 +417,45 @@ def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
             assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
         s.close()
     assert seen >= {0, 1, 2}, seen        # clean prefix, wide helper and fold child all took days
+
+
+def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
+    """k_row_inv_rsp (one workgroup per CU walking the row pairs, next pair's rows prefetched
+    HBM -> LDS, all days of a chained group in one launch) performs the transform and the epilogue
+    of k_row_inv_rs on the same values in the same order: records, flags and statistics must be
+    BIT-identical with PS_RSP=0 (one-shot kernel), PS_RSP=1 and PS_NO_ROW_BATCH=1 (one launch per
+    day) -- un-flagged chained groups (2, 4, 8 days) and a flagged chain (single days, pad rows
+    that raise the flag, the Parseval skip of quiet pad-only pairs)."""
+    from parasitoids_amd import synthetic
+    R, K, nd = 400, 401, 16
+    N = 2 * R + 1
+    for start in (400, 760):               # no flag (groups of 2, 4, 8, 2 days) / flags from the middle on
+        _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        runs = {}
+        for tag, env in (('oneshot', {'PS_RSP': '0'}), ('persistent', {'PS_RSP': '1'}),
+                         ('per_day', {'PS_RSP': '1', 'PS_NO_ROW_BATCH': '1'})):
+            for k in ('PS_RSP', 'PS_NO_ROW_BATCH'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv('PS_TPIPE', '1')
+            s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+            assert s.fft_len == 1008 and s.full_column
+            s.set_kernels(kernels)
+            s.prof_enable(True, every=1)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            prof = s.prof_read()
+            batched = prof['row_inv_x2'][1] + prof['row_inv_x4'][1] + prof['row_inv_x8'][1]
+            if tag == 'persistent' and start == 400:
+                assert batched >= 3            # the chained groups went through one row launch each
+            if tag != 'persistent':
+                assert batched == 0
+            runs[tag] = ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st])
+            s.close()
+        assert any(f for f, _, _, _ in runs['oneshot'][1]) == (start != 400)
+        for tag in ('persistent', 'per_day'):
+            assert runs[tag][1] == runs['oneshot'][1]
+            for a, b in zip(runs[tag][0], runs['oneshot'][0]):
+                assert np.array_equal(a, b)
