@@ -192,6 +192,8 @@ struct ps_solver {
   // spectra
   DevBuf<cplx> Ahat, Chat, T1, T2, Bhat;
   int chunk_days = 1;
+  DevBuf<int> srange;          // [lo, hi] rows of the state record that hold anything (host-supplied states)
+  bool srange_valid = false;
   // kernels (device COO + dense staging)
   DevBuf<int> krow, kcol;
   DevBuf<double> kval;
@@ -511,14 +513,15 @@ static bool colfull_chains(const ps_solver* s) {
 }
 
 static int fwd2d(ps_solver* s, const double* src, int64_t src_bstride, int src_ld, SrcMap rmap,
-                 SrcMap cmap, cplx* out, int batch, const unsigned long long* pred) {
-  // zero source rows are neither written by the row pass nor read by the first column pass
-  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred, 1));
-  if (s->tpipe) return launch_colfull(s, 1, s->T1.p, out, 0, nullptr, batch, RowLive{1, rmap, nullptr}, pred);
+                 SrcMap cmap, cplx* out, int batch, const unsigned long long* pred, const int* rowrange = nullptr) {
+  // zero source rows (outside the row map, or outside [rowrange[0], rowrange[1]] when the caller
+  // knows where the source ends) are neither written by the row pass nor read by the first column pass
+  PS_TRY(launch_row_fwd(s, src, src_bstride, src_ld, rmap, cmap, s->T1.p, batch, pred, 1, rowrange));
+  if (s->tpipe) return launch_colfull(s, 1, s->T1.p, out, 0, nullptr, batch, RowLive{1, rmap, rowrange}, pred);
   if (s->fwd_passes.size() == 1) {
-    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred, RowLive{1, rmap, nullptr}));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, out, batch, 0, pred, RowLive{1, rmap, rowrange}));
   } else {
-    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred, RowLive{1, rmap, nullptr}));
+    PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[0], s->T1.p, nullptr, nullptr, s->T2.p, batch, 0, pred, RowLive{1, rmap, rowrange}));
     PS_TRY(launch_col<PS_FWD>(s, s->fwd_passes[1], s->T2.p, nullptr, nullptr, out, batch, 0, pred));
   }
   return PS_OK;
@@ -1094,6 +1097,7 @@ int ps_solver_set_state_device_coo(ps_solver* s, const int* row, const int* col,
                                    int64_t nnz, int off) {
   PS_TRY(ensure_record(s, PS_REC_STATE, 0));
   PS_TRY(ensure_temps(s, 1));
+  s->srange_valid = false;   // set_state_coo knows the rows and says so afterwards
   double* rec = s->recs[PS_REC_STATE][0];
   PS_HIP(hipMemsetAsync(rec, 0, (size_t)s->N * s->N * sizeof(double), s->stream));
   PS_TRY(scatter_from_device(s, row, col, val, nnz, rec, s->N, off));
@@ -1115,7 +1119,8 @@ static int ensure_spectrum(ps_solver* s) {
   if (s->spec_valid || s->mode == PS_MODE_FOLD) return PS_OK;
   if (s->recs[PS_REC_STATE].empty() || !s->recs[PS_REC_STATE][0]) return ps_fail(PS_ERR_STATE, "no state record");
   PS_TRY(ensure_temps(s, 1));
-  PS_TRY(fwd2d(s, s->recs[PS_REC_STATE][0], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), s->Ahat.p, 1, nullptr));
+  PS_TRY(fwd2d(s, s->recs[PS_REC_STATE][0], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), s->Ahat.p, 1, nullptr,
+               s->srange_valid ? s->srange.p : nullptr));
   s->spec_valid = true;
   return PS_OK;
 }
@@ -1137,7 +1142,20 @@ extern "C" int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const i
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(check_coo(row, col, nnz, s->N, "state"));
   PS_TRY(upload_coo(s, row, col, val, nnz));
-  return ps_solver_set_state_device_coo(s, s->orow.p, s->ocol.p, s->oval.p, nnz, 0);
+  PS_TRY(ps_solver_set_state_device_coo(s, s->orow.p, s->ocol.p, s->oval.p, nnz, 0));
+  // rows that hold anything: a release state is a handful of rows of the N, and the forward row
+  // pass (145 us at 4097^2 for all of them) only has to transform those
+  int range[2] = {1, 0};
+  for (int64_t i = 0; i < nnz; ++i) {
+    if (range[0] > range[1]) range[0] = range[1] = row[i];
+    range[0] = std::min(range[0], (int)row[i]);
+    range[1] = std::max(range[1], (int)row[i]);
+  }
+  PS_TRY(s->srange.ensure(2));
+  PS_HIP(hipMemcpyAsync(s->srange.p, range, sizeof(range), hipMemcpyHostToDevice, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));   // `range` is on this stack
+  s->srange_valid = true;
+  return PS_OK;
 }
 
 // compact day kernels (few live rows per residue class of the column split) can take the
@@ -1402,6 +1420,7 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
         PS_TRY(ensure_record(c, PS_REC_STATE, 0));
         PS_HIP(hipMemcpyAsync(c->recs[PS_REC_STATE][0], prev, (size_t)s->N * s->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         c->spec_valid = false;
+        c->srange_valid = false;   // a whole field: every row may hold something
         c->have_state = true;
         wide_live = true;
         child_live = false;
