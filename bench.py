@@ -46,7 +46,7 @@ DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8,
                    'row_inv_x2': 2, 'row_inv_x4': 4, 'row_inv_x8': 8}
 # kernel class -> (kernel symbol prefixes in the rocprofv3 PMC summaries under profiles/, days per
 # launch or None).  The multi-day launches of the full-column pipeline are ONE kernel each; the
-# summaries tell them apart by the LDS size of the dispatch (scripts/hbm_traffic.py: lds_rank).
+# summaries tell them apart by the bytes they write (scripts/hbm_traffic.py: size_rank).
 PMC_NAME = {'row_inv': (('void k_row_inv',), None), 'col_inv_b': (('void k_col<1',), None),
             'col_inv_a': (('void k_col_fused<', 'void k_colfull_day<'), None)}
 for _n in (2, 4, 8):
@@ -90,9 +90,9 @@ def pmc_traffic(kernel_class):
         if not e['kernel'].startswith(names) or e.get('write_size_MB') is None:
             continue
         if days is not None and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
-            # groups of this kernel by LDS size are its 2-, 4-, 8-day launches in that order; a
-            # summary that does not hold all three cannot be attributed
-            if e.get('lds_groups') != 3 or e.get('lds_rank') != (2, 4, 8).index(days):
+            # the clusters of this kernel's dispatches by bytes written are its 2-, 4-, 8-day
+            # launches in that order; a summary that does not hold all three cannot be attributed
+            if e.get('size_groups') != 3 or e.get('size_rank') != (2, 4, 8).index(days):
                 continue
         if best is None or e['dispatches'] > best['dispatches']:
             best = e

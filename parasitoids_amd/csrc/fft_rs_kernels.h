@@ -205,7 +205,7 @@ struct RsPLds {
   using Y = RsInvLds<R1, R2, R3>;
   static constexpr int HS = (S::L / 2 + 1 + 63) & ~63;   // a staged row: whole 64-element chunks
   static constexpr size_t bytes = (size_t)(Y::XW + Y::RED) * sizeof(double) + 2 * (size_t)HS * sizeof(cplx);
-  static constexpr bool fits = bytes + 3 * 2048 <= (size_t)160 * 1024;   // + the launch tag (PS_LDS_TAG, rs_cfg.h)
+  static constexpr bool fits = bytes <= (size_t)160 * 1024;
 };
 
 template <int R1, int R2, int R3>

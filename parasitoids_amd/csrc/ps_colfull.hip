@@ -14,7 +14,7 @@ int rs_colfull_set_attrs() {
                            (const void*)k_colfull<16, A, B, false, 2>, (const void*)k_colfull<16, A, B, false, 3>, \
                            (const void*)k_colfull<16, A, B, C::CHAIN, 0>};                                   \
       for (const void* kk : kc)                                                                              \
-        if (hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDSC + (C::CHAIN ? 3 * PS_LDS_TAG : 0))) != hipSuccess) return -1; \
+        if (hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDSC) != hipSuccess) return -1; \
     }                                                                                                        \
   }
   PS_RS_SIZES(X)
@@ -38,7 +38,7 @@ int rs_launch_colfull(int r2, int r3, const ColFullArgs& a, int lines8, int batc
     const bool chained = a.mode == 0 && a.nd > 1;                                                      \
     if (chained && !C::CHAIN) return 0;                                                                \
     auto kern = chained ? kc : (a.mode == 0 ? k0 : a.mode == 1 ? k1 : a.mode == 2 ? k2 : k3);          \
-    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), chained ? C::LDSC + ps_lds_tag(a.nd) : C::LDSC1, st, a); \
+    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), chained ? C::LDSC : C::LDSC1, st, a); \
     return 1;                                                                                          \
   }
   PS_RS_SIZES(X)

@@ -39,7 +39,7 @@ int rs_rows_set_attrs() {
     using Z = RsPLds<16, A, B>;                                                                              \
     if constexpr (Z::fits) {                                                                                 \
       auto kp = k_row_inv_rsp<16, A, B>;                                                                     \
-      if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Z::bytes + 3 * PS_LDS_TAG)) != hipSuccess) return -1; \
+      if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z::bytes) != hipSuccess) return -1; \
     }                                                                                                        \
     if (C::LDS > 48 * 1024) {                                                                                \
       auto ki = k_row_inv_rs<16, A, B, np>;                                                                  \
@@ -96,9 +96,14 @@ int rs_launch_row_inv(int r2, int r3, const RowInvArgs& a, int npairs, int batch
     if constexpr (Z::fits) {                                                                                 \
       if (a.persistent && a.tstride == 0) {                                                                  \
         const int units = npairs * batch;                                                                    \
-        const int wgs = units < device_cus() ? units : device_cus();                                         \
+        /* resident workgroups per CU: 8 wave slots at the kernel's ~210 registers, 160 KB of LDS */         \
+        constexpr int W = C::S::NTHR / 64;                                                                   \
+        constexpr int kw = 8 / W < 1 ? 1 : 8 / W, kl = (int)((size_t)160 * 1024 / Z::bytes);                 \
+        constexpr int per_cu = kw < kl ? kw : kl;                                                            \
+        const int slots = device_cus() * per_cu;                                                             \
+        const int wgs = units < slots ? units : slots;                                                       \
         auto kp = k_row_inv_rsp<16, A, B>;                                                                   \
-        hipLaunchKernelGGL(kp, dim3(wgs), dim3(C::S::NTHR), Z::bytes + ps_lds_tag(a.nrec), st, a, npairs, units); \
+        hipLaunchKernelGGL(kp, dim3(wgs), dim3(C::S::NTHR), Z::bytes, st, a, npairs, units); \
         return 1;                                                                                            \
       }                                                                                                      \
     }                                                                                                        \

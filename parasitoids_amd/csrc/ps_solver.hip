@@ -420,7 +420,8 @@ static bool row_inv_persistent(const ps_solver* s) {
   // the column sub-pass just before): the one-shot kernel reads it at 108 us per day where this one
   // needs 126.  The full-column pipeline writes whole groups of days first, the rows come from HBM,
   // and the prefetch wins (127 against 144 us).
-  return knob == 1 || s->tpipe;
+  // (below ~1500 points a row pair is two waves: nothing to gain, -2 % on the R = 400 Bayes chain)
+  return knob == 1 || (s->tpipe && s->Pf >= 1536);
 }
 
 // `recs_multi` != nullptr: batch entry b writes recs_multi[b] (separately allocated day records;

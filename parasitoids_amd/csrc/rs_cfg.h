@@ -4,9 +4,6 @@
 #include "fft_rs_kernels.h"
 #include "fft_rs_sizes.h"
 
-#define PS_LDS_TAG 2048
-static inline size_t ps_lds_tag(int n) { return (size_t)PS_LDS_TAG * (n >= 8 ? 3 : n >= 4 ? 2 : n >= 2 ? 1 : 0); }
-
 template <int R2, int R3>
 struct RsCfg {
   using S = Rs<16, R2, R3>;
@@ -17,8 +14,6 @@ struct RsCfg {
   // full-column pass: one column per workgroup; the state column is parked in LDS next to the
   // exchange buffer when both fit (k_colfull CHAIN)
   static constexpr size_t LDSC1 = RsInvLds<16, R2, R3>::bytes(1);
-  // (+ PS_LDS_TAG bytes per doubling of the days in a launch: rocprofv3 reports the LDS size of every
-  // dispatch, which is how the PMC summaries tell 2-, 4- and 8-day launches of one kernel apart)
-  static constexpr bool CHAIN = LDSC1 + (size_t)S::L * sizeof(cplx) + 3 * PS_LDS_TAG <= (size_t)160 * 1024;
+  static constexpr bool CHAIN = LDSC1 + (size_t)S::L * sizeof(cplx) <= (size_t)160 * 1024;
   static constexpr size_t LDSC = CHAIN ? LDSC1 + (size_t)S::L * sizeof(cplx) : LDSC1;
 };

@@ -1,9 +1,12 @@
 """Build profiles/*_hbm_traffic_pmc.json from two rocprofv3 counter passes (FETCH_SIZE and
 WRITE_SIZE cannot share a pass on gfx950).  FETCH_SIZE is reported in KB and counts 64 B per
 128-B request on gfx950, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is KB.
-Dispatches are grouped by (kernel, grid, LDS size): the multi-day launches of one kernel differ only
-in their LDS size (PS_LDS_TAG, csrc/rs_cfg.h); `days` is the rank of the LDS size among the groups
-of that kernel and grid (1, 2, 4, 8 days per launch).
+Dispatches are grouped by (kernel, grid).  The multi-day launches of the full-column pipeline are
+ONE kernel and one grid whatever the number of days (rocprofv3 reports neither the kernel arguments
+nor the dynamic LDS size), so a group whose WRITE_SIZE values fall into separate clusters (more
+than 25 % apart) is split into them; `size_rank` / `size_groups` say which cluster an entry is
+(ascending bytes: 2, 4, 8 days per launch).  Both passes run the same deterministic command, so the
+k-th dispatch of a kernel in the FETCH pass is the k-th in the WRITE pass.
 usage: hbm_traffic.py FETCH_DIR WRITE_DIR OUT.json"""
 import csv
 import glob
@@ -14,35 +17,48 @@ from collections import defaultdict
 
 
 def read(d, counter):
-    acc = defaultdict(lambda: [0.0, set(), 0])
+    acc = defaultdict(dict)   # (kernel, grid) -> {dispatch id: value}
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if row['Counter_Name'] != counter:
                     continue
-                key = (row['Kernel_Name'].split('(')[0], int(row['Grid_Size']), int(row.get('LDS_Block_Size') or 0))
-                acc[key][0] += float(row['Counter_Value'])
-                acc[key][1].add(row['Dispatch_Id'])
-                acc[key][2] = int(row['Grid_Size'])
-    return acc
+                key = (row['Kernel_Name'].split('(')[0], int(row['Grid_Size']))
+                did = int(row['Dispatch_Id'])
+                acc[key][did] = acc[key].get(did, 0.0) + float(row['Counter_Value'])
+    return {k: [v[i] for i in sorted(v)] for k, v in acc.items()}   # in dispatch order
+
+
+def clusters(vals):
+    """indices of `vals` grouped into clusters of similar size (neighbours within 25 %), ascending"""
+    order = sorted(range(len(vals)), key=lambda i: vals[i])
+    out = [[order[0]]]
+    for i in order[1:]:
+        if vals[i] > 1.25 * vals[out[-1][-1]] and vals[i] > 1.0:
+            out.append([])
+        out[-1].append(i)
+    return out
 
 
 def main(fd, wd, out):
     f = read(fd, 'FETCH_SIZE')
     w = read(wd, 'WRITE_SIZE')
     res = []
-    for key in sorted(f, key=lambda k: -len(f[k][1])):
-        n = len(f[key][1])
-        fetch_mb = f[key][0] / n / 1024.0          # KB -> MB per dispatch
-        ldss = sorted({k[2] for k in f if k[:2] == key[:2]})
-        e = {'kernel': key[0], 'grid': key[1], 'lds_block': key[2],
-             'lds_rank': ldss.index(key[2]), 'lds_groups': len(ldss),
-             'dispatches': n, 'fetch_size_MB': fetch_mb,
-             'fetch_corrected_MB': 2.0 * fetch_mb,
-             'write_size_MB': (w[key][0] / max(1, len(w[key][1])) / 1024.0) if key in w else None}
-        res.append(e)
+    for key in sorted(f, key=lambda k: -len(f[k])):
+        fv, wv = f[key], w.get(key)
+        groups = [list(range(len(fv)))]
+        if wv is not None and len(wv) == len(fv) and len(fv) > 1:
+            groups = clusters(wv)
+        for rank, idx in enumerate(groups):
+            n = len(idx)
+            fetch_mb = sum(fv[i] for i in idx) / n / 1024.0          # KB -> MB per dispatch
+            e = {'kernel': key[0], 'grid': key[1], 'size_rank': rank, 'size_groups': len(groups),
+                 'dispatches': n, 'fetch_size_MB': fetch_mb, 'fetch_corrected_MB': 2.0 * fetch_mb,
+                 'write_size_MB': (sum(wv[i] for i in idx) / n / 1024.0) if wv is not None and len(wv) == len(fv)
+                 else ((sum(wv) / len(wv) / 1024.0) if wv else None)}
+            res.append(e)
     json.dump(res, open(out, 'w'), indent=1)
-    for e in res[:8]:
+    for e in res[:10]:
         print(e)
 
 

@@ -230,3 +230,35 @@ def test_committed_bench_line_keeps_the_contract():
     assert d['parity']['ok'] is True
     # value and ms_per_step describe the same run: 30-day stacks
     assert abs(d['value'] - d['n_gpus'] * d['config']['ndays'] / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
+
+
+def test_hbm_traffic_splits_multi_day_launches_by_bytes_written(tmp_path):
+    """scripts/hbm_traffic.py: dispatches of one kernel and grid whose WRITE_SIZE falls into
+    separate clusters (the 2-, 4-, 8-day launches of the chained full-column pass) become separate
+    entries with size_rank 0, 1, 2; FETCH_SIZE follows by dispatch order and is doubled."""
+    import csv
+    import json as _json
+    import subprocess
+    import sys
+    hdr = ['Dispatch_Id', 'Grid_Size', 'Kernel_Name', 'LDS_Block_Size', 'Counter_Name', 'Counter_Value']
+    days = [2, 4, 8, 8, 8, 2, 4, 8, 8, 8]
+    for name, counter, per_day in (('f', 'FETCH_SIZE', 40e3), ('w', 'WRITE_SIZE', 200e3)):
+        d = tmp_path / name
+        d.mkdir()
+        with open(d / 'x_counter_collection.csv', 'w', newline='') as fh:
+            wr = csv.writer(fh)
+            wr.writerow(hdr)
+            for i, n in enumerate(days):
+                for xcd in range(2):     # a counter arrives in several rows per dispatch
+                    wr.writerow([10 + i, 1000, 'void k_colfull<16, 18, 18, true, 0>(ColFullArgs)', 0, counter,
+                                 (n * per_day + 100e3) / 2])
+            wr.writerow([99, 512, 'k_other(int)', 0, counter, 1024.0])
+    out = tmp_path / 'o.json'
+    subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'hbm_traffic.py'), str(tmp_path / 'f'),
+                    str(tmp_path / 'w'), str(out)], check=True, capture_output=True)
+    res = [e for e in _json.load(open(out)) if e['kernel'].startswith('void k_colfull<')]
+    assert [e['size_rank'] for e in res] == [0, 1, 2] and all(e['size_groups'] == 3 for e in res)
+    assert [e['dispatches'] for e in res] == [2, 2, 6]
+    for e, n in zip(res, (2, 4, 8)):
+        assert abs(e['write_size_MB'] - (n * 200e3 + 100e3) / 1024.0) < 1e-9
+        assert abs(e['fetch_corrected_MB'] - 2 * (n * 40e3 + 100e3) / 1024.0) < 1e-9
