@@ -89,6 +89,8 @@ def pmc_traffic(kernel_class):
     for e in json.load(open(files[-1])):
         if not e['kernel'].startswith(names) or e.get('write_size_MB') is None:
             continue
+        if days is None and e.get('size_groups', 1) != 1:
+            continue      # a kernel whose dispatches differ in size: not a single-day class
         if days is not None and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
             # the clusters of this kernel's dispatches by bytes written are its 2-, 4-, 8-day
             # launches in that order; a summary that does not hold all three cannot be attributed
@@ -322,7 +324,9 @@ def main():
                 model_p2[k] += 8.0 * n
             model_p2['col_inv_a'] += 8.0
         fl = solver.fft_len
-        krows = K * (fl // 2 + 1) * 16.0   # the K row-pass rows of one day kernel (half spectra)
+        # the row-pass rows of one day kernel that hold anything (half spectra), averaged over the days
+        live = [(int(k.row.max()) - int(k.row.min()) + 1) if k.nnz else 0 for k in kernels]
+        krows = float(np.mean(live)) * (fl // 2 + 1) * 16.0
         for k, (ms, cnt) in prof.items():
             if cnt:
                 avg = ms / cnt
@@ -379,6 +383,16 @@ def main():
                                             'collected in this run)' % traffic_src) if traffic_src else None},
             'kernels': kern,
         }
+        if dom.startswith('col_inv_a') and solver.full_column:
+            # the full-column day pass is two length-L complex transforms and one product per column
+            # and day: what its time is spent on (nominal 5 L log2 L flops per transform); the fp64
+            # vector peak is the guide's 78.6 TFLOP/s.  Neither roof is near: see DESIGN.md 4.1c.
+            import math
+            ncol = fl // 2 + 1
+            flops = DAYS_PER_LAUNCH.get(dom, 1) * ncol * (2 * 5.0 * fl * math.log2(fl) + 6.0 * fl)
+            tf = flops / (kern[dom]['avg_ms'] * 1e-3) / 1e12
+            out['roofline']['fp64_valu'] = {'flops_per_launch': flops, 'achieved': round(tf, 2), 'peak': 78.6,
+                                            'unit': 'TFLOP/s', 'frac': round(tf / 78.6, 4)}
         if nranks == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'], ofields = cpu_baseline(state, kernels, K, args.cpu_days)
             # parity at the benchmarked configuration: the oracle's raw day fields against the
