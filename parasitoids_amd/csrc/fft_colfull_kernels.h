@@ -56,7 +56,7 @@ struct ColFullArgs {
 // compiler turns into 162 registers and no scratch (255 us per day at L = 5184).  The templated
 // kernel below serves the other modes (114-128 registers) and the chained groups of days; its
 // one-day instance costs 246-256 registers and is 15-45 % slower than this one.
-template <int R1, int R2, int R3>
+template <int R1, int R2, int R3, bool CEX>
 __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullArgs a) {
   using S = Rs<R1, R2, R3>;
   constexpr int L = S::L;
@@ -66,6 +66,9 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
   const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
   if (c >= a.ncols) return;   // whole workgroup: no barrier is pending
+  // CEX: complex exchange words (rs_tail_c: 3 barriers per transform, 8 for the whole day step
+  // instead of 21); the buffer is then 17 L bytes, which sizes beyond 9400 do not have
+  cplx* exc = reinterpret_cast<cplx*>(ps_lds_raw);
   double* ex = reinterpret_cast<double*>(ps_lds_raw);
   const int j = threadIdx.x;
   const FftProg& P = a.prog;
@@ -84,7 +87,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
       }
       bfly<R1, PS_FWD>(x);
     }
-    rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);   // thread j < T3: X[j + q T3]
+    if constexpr (CEX) rs_tail_c<S, R1, R2, R3, PS_FWD>(x, exc, j, w2, w3);   // thread j < T3: X[j + q T3]
+    else rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);
     if (a.mode == 1) {
       if (j < S::T3) {
 #pragma unroll
@@ -103,26 +107,38 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
       }
     }
     if (a.mode == 3) return;
-    // natural order (j + q T3) -> first-stage input order (j + q T1), real parts then imaginary
+    // natural order (j + q T3) -> first-stage input order (j + q T1) through the exchange buffer
     __syncthreads();
-    if (j < S::T3) {
+    if constexpr (CEX) {
+      if (j < S::T3) {
 #pragma unroll
-      for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].x;
-    }
-    __syncthreads();
-    if (j < S::T1) {
+        for (int q = 0; q < R3; ++q) exc[j + q * S::T3] = x[q];
+      }
+      __syncthreads();
+      if (j < S::T1) {
 #pragma unroll
-      for (int q = 0; q < R1; ++q) x[q].x = ex[j + q * S::T1];
-    }
-    __syncthreads();
-    if (j < S::T3) {
+        for (int q = 0; q < R1; ++q) x[q] = exc[j + q * S::T1];
+      }
+    } else {   // real parts, then imaginary parts
+      if (j < S::T3) {
 #pragma unroll
-      for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].y;
-    }
-    __syncthreads();
-    if (j < S::T1) {
+        for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].x;
+      }
+      __syncthreads();
+      if (j < S::T1) {
 #pragma unroll
-      for (int q = 0; q < R1; ++q) x[q].y = ex[j + q * S::T1];
+        for (int q = 0; q < R1; ++q) x[q].x = ex[j + q * S::T1];
+      }
+      __syncthreads();
+      if (j < S::T3) {
+#pragma unroll
+        for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = x[q].y;
+      }
+      __syncthreads();
+      if (j < S::T1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) x[q].y = ex[j + q * S::T1];
+      }
     }
     __syncthreads();
   } else if (j < S::T1) {
@@ -130,7 +146,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
     for (int q = 0; q < R1; ++q) x[q] = st[j + q * S::T1];
   }
   if (j < S::T1) bfly<R1, PS_INV>(x);
-  rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);     // thread j < T3: spatial rows j + q T3
+  if constexpr (CEX) rs_tail_c<S, R1, R2, R3, PS_INV>(x, exc, j, w2, w3);     // thread j < T3: spatial rows j + q T3
+  else rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
   if (j < S::T3) {
     cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (a.dst_t ? (int64_t)c * L : (int64_t)c);
     const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;

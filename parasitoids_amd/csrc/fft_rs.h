@@ -126,4 +126,33 @@ __device__ __forceinline__ void rs_tail(cplx* x, double* ex, const int j, const 
   if (j < S::T3) rs_stage<R3, DIR>(x, w3, true);
 }
 
+
+// The same two exchanges with COMPLEX words (16 bytes: buffer 2 x XWORDS doubles): real and
+// imaginary parts travel together, so an exchange is put -> barrier -> get and the transform has 3
+// barriers instead of 8 and half the LDS instructions.  Same index maps: with 16-byte words the
+// i + (i >> 4) padding spreads 16 consecutive words over all 64 banks.  For the kernels that own
+// their CU's LDS anyway (the buffer is 17 L bytes: 88 KB at 5184).
+template <int R>
+__device__ __forceinline__ void rs_putc(cplx* ex, int base, int stride, const cplx* x) {
+#pragma unroll
+  for (int q = 0; q < R; ++q) ex[base + q * stride] = x[q];
+}
+template <int R>
+__device__ __forceinline__ void rs_getc(const cplx* ex, int base, int stride, cplx* x) {
+#pragma unroll
+  for (int q = 0; q < R; ++q) x[q] = ex[base + q * stride];
+}
+template <class S, int R1, int R2, int R3, int DIR, bool RAW = false>
+__device__ __forceinline__ void rs_tail_c(cplx* x, cplx* ex, const int j, const cplx w2, const cplx w3) {
+  if (j < S::T1) rs_putc<R1>(ex, S::x1_w(j), 1, x);
+  rs_bar<RAW>();
+  if (j < S::T2) rs_getc<R2>(ex, S::x_r(j), S::X1_RS, x);
+  if (j < S::T2) rs_stage<R2, DIR>(x, w2, true);
+  rs_bar<RAW>();
+  if (j < S::T2) rs_putc<R2>(ex, S::x2_w(j), 17, x);
+  rs_bar<RAW>();
+  if (j < S::T3) rs_getc<R3>(ex, S::x_r(j), S::X2_RS, x);
+  if (j < S::T3) rs_stage<R3, DIR>(x, w3, true);
+}
+
 #endif

@@ -9,12 +9,12 @@ int rs_colfull_set_attrs() {
 #define X(A, B)                                                                                              \
   {                                                                                                          \
     using C = RsCfg<A, B>;                                                                                   \
-    if (C::LDSC > 48 * 1024) {                                                                               \
-      const void* kc[5] = {(const void*)k_colfull_day<16, A, B>, (const void*)k_colfull<16, A, B, false, 1>, \
+    if (C::LDSC > 48 * 1024 || C::LDSD > 48 * 1024) {                                                        \
+      const void* kc[5] = {(const void*)k_colfull_day<16, A, B, C::CEX>, (const void*)k_colfull<16, A, B, false, 1>, \
                            (const void*)k_colfull<16, A, B, false, 2>, (const void*)k_colfull<16, A, B, false, 3>, \
                            (const void*)k_colfull<16, A, B, C::CHAIN, 0>};                                   \
       for (const void* kk : kc)                                                                              \
-        if (hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDSC) != hipSuccess) return -1; \
+        if (hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDSC > C::LDSD ? C::LDSC : C::LDSD)) != hipSuccess) return -1; \
     }                                                                                                        \
   }
   PS_RS_SIZES(X)
@@ -30,7 +30,7 @@ int rs_launch_colfull(int r2, int r3, const ColFullArgs& a, int lines8, int batc
     using C = RsCfg<A, B>;                                                                             \
     /* single passes take the state straight from HBM (162 registers, 255 us per day at 5184); only a  \
        group of chained days parks it in LDS (246 registers: 294 us for one day, 218 per day for eight) */ \
-    auto k0 = k_colfull_day<16, A, B>;                                                                 \
+    auto k0 = k_colfull_day<16, A, B, C::CEX>;                                                                 \
     auto k1 = k_colfull<16, A, B, false, 1>;                                                           \
     auto k2 = k_colfull<16, A, B, false, 2>;                                                           \
     auto k3 = k_colfull<16, A, B, false, 3>;                                                           \
@@ -38,7 +38,7 @@ int rs_launch_colfull(int r2, int r3, const ColFullArgs& a, int lines8, int batc
     const bool chained = a.mode == 0 && a.nd > 1;                                                      \
     if (chained && !C::CHAIN) return 0;                                                                \
     auto kern = chained ? kc : (a.mode == 0 ? k0 : a.mode == 1 ? k1 : a.mode == 2 ? k2 : k3);          \
-    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), chained ? C::LDSC : C::LDSC1, st, a); \
+    hipLaunchKernelGGL(kern, grid, dim3(C::S::NTHR), chained ? C::LDSC : (a.mode == 0 ? C::LDSD : C::LDSC1), st, a); \
     return 1;                                                                                          \
   }
   PS_RS_SIZES(X)

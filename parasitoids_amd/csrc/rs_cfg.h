@@ -16,4 +16,7 @@ struct RsCfg {
   static constexpr size_t LDSC1 = RsInvLds<16, R2, R3>::bytes(1);
   static constexpr bool CHAIN = LDSC1 + (size_t)S::L * sizeof(cplx) <= (size_t)160 * 1024;
   static constexpr size_t LDSC = CHAIN ? LDSC1 + (size_t)S::L * sizeof(cplx) : LDSC1;
+  // single-day pass: complex exchange words (rs_tail_c) when the doubled buffer fits
+  static constexpr bool CEX = 2 * LDSC1 <= (size_t)160 * 1024;
+  static constexpr size_t LDSD = CEX ? 2 * LDSC1 : LDSC1;
 };
