@@ -242,3 +242,39 @@ def test_bayes_funcs_projection_against_a_loop_restatement(golden):
         np.testing.assert_allclose(rel2[i], rel[i], rtol=1e-14, atol=1e-10)
         np.testing.assert_allclose(sen2[i], sen[i], rtol=1e-14, atol=1e-10)
     assert np.array_equal(grid2, grid)
+
+
+def test_likelihood_statistics_equal_the_array_form(golden):
+    """loglik_parts_stats (sufficient statistics of one evaluation, what the scalar Metropolis steps
+    use) against loglik_parts (the rates written out, Bayes_Run.py:344-433): same values to
+    round-off for random nuisance values, -inf in the same places (zero base rate under a positive
+    count, non-positive scalars)."""
+    g = golden('g9_bayes_funcs')
+    li, cell_area = g9_locinfo(g)
+    rng = np.random.default_rng(3)
+    exp = ([g['rel0'], g['rel1']], [g['sen0'], g['sen1']], g['grid'])
+    st = mcmc.lik_stats(exp, li)
+    nf = len(mcmc.initial_sent_obs_probs(li, cell_area))
+    for _ in range(50):
+        nuis = np.array([rng.uniform(0.1, 3.0), rng.uniform(0.01, 0.9), rng.uniform(1e-4, 0.1)])
+        sp = rng.uniform(0.01, 0.9, nf)
+        a = mcmc.loglik_parts(exp, li, nuis, sp)
+        b = mcmc.loglik_parts_stats(st, nuis, sp)
+        for x, y in zip(a, b):
+            assert (x == y == mcmc.NEG_INF) or abs(x - y) <= 1e-10 * max(1.0, abs(x)), (x, y)
+    # non-positive scalars
+    for nuis, sp in ((np.array([-1.0, 0.5, 0.01]), np.full(nf, 0.1)), (np.array([1.0, 0.5, -0.01]), np.full(nf, 0.1)),
+                     (np.array([1.0, 0.5, 0.01]), np.r_[-0.1, np.full(nf - 1, 0.1)])):
+        a = mcmc.loglik_parts(exp, li, nuis, sp)
+        b = mcmc.loglik_parts_stats(st, nuis, sp)
+        assert [x == mcmc.NEG_INF for x in a] == [y == mcmc.NEG_INF for y in b]
+    # a zero base rate where something was observed
+    rel0 = np.array(g['rel0'], dtype=np.float64)
+    obs0 = np.asarray(li.release_emerg[0], dtype=np.float64)
+    hit = np.argwhere(obs0 > 0)
+    if len(hit):
+        rel0[tuple(hit[0])] = 0.0
+        exp2 = ([rel0, g['rel1']], exp[1], exp[2])
+        nuis, sp = np.array([1.0, 0.5, 0.01]), np.full(nf, 0.1)
+        assert mcmc.loglik_parts(exp2, li, nuis, sp)[0] == mcmc.NEG_INF
+        assert mcmc.loglik_parts_stats(mcmc.lik_stats(exp2, li), nuis, sp)[0] == mcmc.NEG_INF
