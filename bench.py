@@ -376,6 +376,10 @@ def main():
                                           if traffic else None),
                          'traffic_frac': (round(traffic / (kern[dom]['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                           if traffic else None),
+                         # SURVEY 8d's unfused model for the same launch (48 P^2 per grid-day of the fused day
+                         # pass): what an implementation that streamed every intermediate would have to move
+                         'survey_model_GBps': kern[dom]['model_GBps'],
+                         'survey_model_frac': round(kern[dom]['model_GBps'] / HBM_PEAK_GBS, 4),
                          'bytes_per_launch': kern[dom].get('bytes_per_launch'),
                          'days_per_launch': DAYS_PER_LAUNCH.get(dom, 1),
                          'avg_launch_ms': kern[dom]['avg_ms'],
