@@ -17,11 +17,11 @@ struct RsCfg {
   static constexpr bool CHAIN = LDSC1 + (size_t)S::L * sizeof(cplx) <= (size_t)160 * 1024;
   static constexpr size_t LDSC = CHAIN ? LDSC1 + (size_t)S::L * sizeof(cplx) : LDSC1;
   // single-day pass: complex exchange words (rs_tail_c) when the doubled buffer fits
-  // OFF: with it the single-day pass is 3.5 % (5600) to 13 % (8400) faster, but the compiler then
-  // contracts the transform's multiply-adds differently from the chained pass (which has no LDS for
-  // complex words): the two differ in the last bit, and a chain that rolls back to single-day
-  // passes after a flag would no longer be bit-identical to the non-speculative chain
-  // (test_flag_speculation_is_exact_in_the_full_column_pipeline).
-  static constexpr bool CEX = false && 2 * LDSC1 <= (size_t)160 * 1024;
+  // (The library is built with -ffp-contract=on: multiply-adds are contracted where the SOURCE
+  // writes them in one expression, not where the optimiser finds them.  With the default `fast`
+  // this pass and the chained pass -- real exchange words, no LDS for complex ones -- came out one
+  // bit apart, and a chain rolling back to single-day passes after a flag must stay bit-identical
+  // to the non-speculative chain: test_flag_speculation_is_exact_in_the_full_column_pipeline.)
+  static constexpr bool CEX = 2 * LDSC1 <= (size_t)160 * 1024;
   static constexpr size_t LDSD = CEX ? 2 * LDSC1 : LDSC1;
 };
