@@ -182,6 +182,11 @@ struct ps_solver {
   int fused_days = getenv("PS_FUSED_DAYS") ? atoi(getenv("PS_FUSED_DAYS")) : 8;   // days per fused column pass (1, 2, 4, 8)
   int spec_window = 1;
   hipEvent_t spec_ev[2] = {nullptr, nullptr};
+  // second stream: the kernel transforms of the later days of a chunk run there, behind the
+  // first windows of day passes (see chain_run); kt_from = first day whose transform is pending
+  hipStream_t stream2 = nullptr;
+  hipEvent_t kt_ev = nullptr, kt_ev0 = nullptr;
+  int kt_from = -1;
   unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
   int hflags_n = 0;
   int rs_r2 = 0, rs_r3 = 0;   // register-resident row kernels (fft_rs.h) for Pf = 16 * rs_r2 * rs_r3, or 0
@@ -975,6 +980,12 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
     s->stream = nullptr;
     for (auto& p : s->recs[PS_REC_CHAIN]) p = nullptr;
   }
+  if (s->stream2) {
+    (void)hipStreamSynchronize(s->stream2);
+    (void)hipStreamDestroy(s->stream2);
+  }
+  if (s->kt_ev) (void)hipEventDestroy(s->kt_ev);
+  if (s->kt_ev0) (void)hipEventDestroy(s->kt_ev0);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   ps_dev_quiesce();
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
@@ -1177,12 +1188,16 @@ static bool day_is_compact(const ps_solver* s, int d) {
 }
 
 // transform `count` kernels starting at day `first` into Bhat[0..count)
-static int transform_kernels(ps_solver* s, int first, int count) {
+// The transforms go to slots [slot0, slot0 + count) of buffers sized for `total` slots (a chunk
+// transformed in two parts: the second part on the second stream).
+static int transform_kernels(ps_solver* s, int first, int count, int slot0 = 0, int total = -1) {
   const int K = s->Kmax, M = K / 2;
   const size_t spec = (size_t)s->Pf * s->ld;
-  PS_TRY(s->kdense.ensure((size_t)count * K * K));
-  PS_TRY(s->Bhat.ensure(spec * count));
-  PS_TRY(ensure_temps(s, count));
+  if (total < 0) total = count;
+  PS_TRY(s->kdense.ensure((size_t)total * K * K));
+  PS_TRY(s->Bhat.ensure(spec * total));
+  PS_TRY(ensure_temps(s, total));
+  double* kd = s->kdense.p + (size_t)slot0 * K * K;
   // zero only the band of staging rows some kernel of the chunk writes (the row pass reads
   // nothing else, see krange) with one small kernel, then one batched scatter launch
   int blo = K, bhi = -1;
@@ -1199,14 +1214,14 @@ static int transform_kernels(ps_solver* s, int first, int count) {
     bhi = std::min(bhi, K - 1);
     const int64_t n = (int64_t)(bhi - blo + 1) * K;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_zero_band, dim3(blocks, count), dim3(256), 0, s->stream, s->kdense.p, K, blo, bhi);
+    hipLaunchKernelGGL(k_zero_band, dim3(blocks, count), dim3(256), 0, s->stream, kd, K, blo, bhi);
     PS_HIP(hipGetLastError());
   }
   if (maxn > 0) {
     const int thr = 256;
     const int blocks = (int)std::min<int64_t>((maxn + thr - 1) / thr, 1024);
     hipLaunchKernelGGL(k_scatter_coo_batch, dim3(blocks, count), dim3(thr), 0, s->stream, s->krow.p, s->kcol.p,
-                       s->kval.p, s->dkoff.p, s->dkshape.p, first, s->kdense.p, K);
+                       s->kval.p, s->dkoff.p, s->dkshape.p, first, kd, K);
     PS_HIP(hipGetLastError());
   }
   // compact kernels (few live rows per residue class of the column split): skip the first
@@ -1216,10 +1231,19 @@ static int transform_kernels(ps_solver* s, int first, int count) {
   // its tile, does not gain)
   bool direct = direct_possible(s);
   for (int d = first; d < first + count && direct; ++d) direct = day_is_compact(s, d);
-  PS_TRY(fwd2d_partial(s, s->kdense.p, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p, count,
+  PS_TRY(fwd2d_partial(s, kd, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p + (size_t)slot0 * spec, count,
                        s->krange.p + 2 * first, direct));
-  s->bhat_first = first;
-  s->bhat_count = count;
+  s->bhat_first = first - slot0;
+  s->bhat_count = slot0 + count;
+  return PS_OK;
+}
+
+// main stream: wait for the second stream's kernel transforms before day `d` is used
+static int kernels_ready(ps_solver* s, int d) {
+  if (s->kt_from >= 0 && d >= s->kt_from) {
+    PS_HIP(hipStreamWaitEvent(s->stream, s->kt_ev, 0));
+    s->kt_from = -1;
+  }
   return PS_OK;
 }
 
@@ -1479,8 +1503,21 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   return PS_OK;
 }
 
+static int chain_run_body(ps_solver* s, int first, int count, double negval, double stat_scale, int renorm);
+
 extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_scale,
                             int renorm) {
+  const int rc = chain_run_body(s, first, count, negval, stat_scale, renorm);
+  // whatever path the run took (error, hand-over to a helper before the later days were reached):
+  // nothing of this solver's second stream is left unordered behind the main stream
+  if (s && s->kt_from >= 0) {
+    (void)hipStreamWaitEvent(s->stream, s->kt_ev, 0);
+    s->kt_from = -1;
+  }
+  return rc;
+}
+
+static int chain_run_body(ps_solver* s, int first, int count, double negval, double stat_scale, int renorm) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
   if (!s->have_state) return ps_fail(PS_ERR_STATE, "chain_run before set_state");
   if (!s->kernels_on_device || first < 0 || count < 0 || first + count > s->nk)
@@ -1613,8 +1650,36 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
   PS_TRY(ensure_spectrum(s));
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
-    PS_TRY(transform_kernels(s, c0, cn));
+    // Full-column pipeline, long chunk: only the kernels of the first three windows (2 + 4 + 8 days)
+    // are transformed ahead of the day passes; the rest go to a second, low-priority stream and
+    // run in the CUs the day passes leave idle -- a chained pass has 2593 columns for 256 CUs, its
+    // eleventh round occupies 33 of them -- instead of 0.2 ms up front.
+    static const int split_days = getenv("PS_KT_SPLIT") ? atoi(getenv("PS_KT_SPLIT")) : 14;   // A/B knob: 0 = off
+    if (s->tpipe && s->speculate && split_days > 0 && cn >= split_days + 8) {
+      if (!s->stream2) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = numerically greatest = lowest priority
+        PS_HIP(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, lo));
+        PS_HIP(hipEventCreateWithFlags(&s->kt_ev, hipEventDisableTiming));
+        PS_HIP(hipEventCreateWithFlags(&s->kt_ev0, hipEventDisableTiming));
+      }
+      PS_TRY(transform_kernels(s, c0, split_days, 0, cn));
+      // the second stream starts behind everything the main stream has queued so far (an earlier
+      // run may still be reading these slots)
+      PS_HIP(hipEventRecord(s->kt_ev0, s->stream));
+      PS_HIP(hipStreamWaitEvent(s->stream2, s->kt_ev0, 0));
+      hipStream_t main_stream = s->stream;
+      s->stream = s->stream2;
+      const int rc2 = transform_kernels(s, c0 + split_days, cn - split_days, split_days, cn);
+      s->stream = main_stream;
+      if (rc2 != PS_OK) return rc2;
+      PS_HIP(hipEventRecord(s->kt_ev, s->stream2));
+      s->kt_from = c0 + split_days;
+    } else {
+      PS_TRY(transform_kernels(s, c0, cn));
+    }
     auto day = [&](int d, bool with_refft) -> int {
+      PS_TRY(kernels_ready(s, d));
       const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
       double* rec = s->recs[PS_REC_CHAIN][d];
       PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale, s->krange.p + 2 * d));
@@ -1655,6 +1720,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
                                     : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
           if (maxd > 1 && w - i >= 2) {
             const int nd = (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
+            PS_TRY(kernels_ready(s, d + i + nd - 1));
             const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
             PS_TRY(conv_inv_multi(s, B, nd, s->Ahat.p, &s->recs[PS_REC_CHAIN][d + i], d + i, negval, stat_scale,
                                   s->krange.p + 2 * (d + i), &g));
