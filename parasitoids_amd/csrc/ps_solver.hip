@@ -1654,7 +1654,8 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // are transformed ahead of the day passes; the rest go to a second, low-priority stream and
     // run in the CUs the day passes leave idle -- a chained pass has 2593 columns for 256 CUs, its
     // eleventh round occupies 33 of them -- instead of 0.2 ms up front.
-    static const int split_days = getenv("PS_KT_SPLIT") ? atoi(getenv("PS_KT_SPLIT")) : 14;   // A/B knob: 0 = off
+    const char* kts = getenv("PS_KT_SPLIT");                     // A/B knob (per run: tests flip it): 0 = off
+    const int split_days = kts ? atoi(kts) : 14;
     if (s->tpipe && s->speculate && split_days > 0 && cn >= split_days + 8) {
       if (!s->stream2) {
         int lo = 0, hi = 0;

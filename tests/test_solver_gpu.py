@@ -459,3 +459,41 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
             assert runs[tag][1] == runs['oneshot'][1]
             for a, b in zip(runs[tag][0], runs['oneshot'][0]):
                 assert np.array_equal(a, b)
+
+
+def test_second_stream_kernel_transforms_change_nothing(hip_lib, monkeypatch):
+    """Long chunks in the full-column pipeline transform only the kernels of the first windows
+    ahead of the day passes; the rest run on a second stream behind them (ps_chain_run, PS_KT_SPLIT).
+    Same records, flags and statistics, bit for bit, as with every transform up front -- for a
+    clean 26-day chain, for one that raises its first flag before the second part is needed (the
+    run rolls back to single days while the second stream is still working) and for one that raises
+    it after; and twice in a row on the same solver (the second stream's slots are reused)."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    R, K, nd = 400, 401, 26
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=11, sigma=(6.0, 12.0), shift=6)
+    seen_flags = []
+    for start in (400, 600, 650, 775):
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        runs = {}
+        for tag, split in (('upfront', '0'), ('split', '8')):
+            monkeypatch.setenv('PS_KT_SPLIT', split)
+            s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+            s.set_kernels(kernels)
+            out = []
+            for rep in range(2):
+                s.set_state(state)
+                s.run_chain(renorm=True)
+                st = s.chain_stats(0, nd)
+                out.append(([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st]))
+            assert s.full_column
+            s.close()
+            runs[tag] = out
+        for rep in range(2):
+            assert runs['split'][rep][1] == runs['upfront'][rep][1]
+            for a, b in zip(runs['split'][rep][0], runs['upfront'][rep][0]):
+                assert np.array_equal(a, b)
+        flags = [f for f, _, _, _ in runs['upfront'][0][1]]
+        seen_flags.append(flags.index(1) if 1 in flags else -1)
+    assert seen_flags[0] == -1 and any(f >= 8 for f in seen_flags) and any(0 <= f < 8 for f in seen_flags), seen_flags
