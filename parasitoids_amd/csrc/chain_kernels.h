@@ -304,3 +304,9 @@ static __global__ void k_gather_points(const double* __restrict__ rec, int N, co
     out[i] = (t < negval) ? 0.0 : t;
   }
 }
+
+// two ints by value into device memory (a live-row range the host knows): no staging buffer, no sync
+static __global__ void k_set_int2(int* dst, int a, int b) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { dst[0] = a; dst[1] = b; }
+}
+

@@ -1164,8 +1164,8 @@ extern "C" int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const i
     range[1] = std::max(range[1], (int)row[i]);
   }
   PS_TRY(s->srange.ensure(2));
-  PS_HIP(hipMemcpyAsync(s->srange.p, range, sizeof(range), hipMemcpyHostToDevice, s->stream));
-  PS_HIP(hipStreamSynchronize(s->stream));   // `range` is on this stack
+  hipLaunchKernelGGL(k_set_int2, dim3(1), dim3(64), 0, s->stream, s->srange.p, range[0], range[1]);
+  PS_HIP(hipGetLastError());
   s->srange_valid = true;
   return PS_OK;
 }
