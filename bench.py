@@ -44,6 +44,10 @@ MODEL_P2 = {
 }
 DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8,
                    'row_inv_x2': 2, 'row_inv_x4': 4, 'row_inv_x8': 8}
+# `_xn`: any other number of chained days per launch (a solver whose previous run raised no flag opens
+# with windows of up to 16 days: 15 + 15 for this stack); the library counts the grid-days its timed
+# launches covered (ps_prof_read_days) and main() fills in the average
+VARIABLE_DAYS = ('col_inv_a_xn', 'row_inv_xn')
 # kernel class -> (kernel symbol prefixes in the rocprofv3 PMC summaries under profiles/, days per
 # launch or None).  The multi-day launches of the full-column pipeline are ONE kernel each; the
 # summaries tell them apart by the bytes they write (scripts/hbm_traffic.py: size_rank).
@@ -52,9 +56,11 @@ PMC_NAME = {'row_inv': (('void k_row_inv',), None), 'col_inv_b': (('void k_col<1
 for _n in (2, 4, 8):
     PMC_NAME['col_inv_a_x%d' % _n] = (('void k_col_fused_multi<false, %d,' % _n, 'void k_colfull<'), _n)
     PMC_NAME['row_inv_x%d' % _n] = (('void k_row_inv_rsp<',), _n)
+PMC_NAME['col_inv_a_xn'] = (('void k_colfull<', 'void k_colfull_dual<'), 0)   # 0: the cluster with the most dispatches
+PMC_NAME['row_inv_xn'] = (('void k_row_inv_rsp<',), 0)
 
 
-def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0):
+def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0, days=None):
     """ALGORITHMIC HBM bytes of ONE launch of this implementation's kernel class: what the
     launch has to read and write given that its intermediates stay in LDS --
     the compulsory traffic, which the PMC counters confirm (`roofline.traffic`).
@@ -62,7 +68,7 @@ def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0):
     ld = (fft_len // 2 + 1 + 7) // 8 * 8
     S = fft_len * ld * 16.0
     F = N * N * 8.0
-    nd = DAYS_PER_LAUNCH.get(cls, 1)
+    nd = days if days else DAYS_PER_LAUNCH.get(cls, 1)
     if cls.startswith('col_inv_a'):
         # state in, state out, nd first-inverse-sub-pass outputs; the kernels' side is either
         # their live row-pass rows (direct sum / full-column pipeline) or nd intermediate spectra
@@ -91,7 +97,7 @@ def pmc_traffic(kernel_class):
             continue
         if days is None and e.get('size_groups', 1) != 1:
             continue      # a kernel whose dispatches differ in size: not a single-day class
-        if days is not None and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
+        if days and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
             # the clusters of this kernel's dispatches by bytes written are its 2-, 4-, 8-day
             # launches in that order; a summary that does not hold all three cannot be attributed
             if e.get('size_groups') != 3 or e.get('size_rank') != (2, 4, 8).index(days):
@@ -307,6 +313,7 @@ def main():
     fence()
     dt_own = time.perf_counter() - t0
     prof = solver.prof_read()
+    prof_days = solver.prof_days()
     solver.prof_enable(False)
     dt, per_rank = gather_times(dt_own)
 
@@ -316,11 +323,16 @@ def main():
         value = grid_days / dt
         kern = {}
         model_p2 = dict(MODEL_P2)
+        days_of = dict(DAYS_PER_LAUNCH)
+        for k in VARIABLE_DAYS:
+            if prof.get(k, (0, 0))[1]:
+                days_of[k] = prof_days[k] / prof[k][1]
+                model_p2[k] = (40.0 if k.startswith('col') else 24.0) * days_of[k]
         direct = bool(solver.kernels_direct) or bool(solver.full_column)
         if direct:
             # compact kernels: the first forward column sub-pass (col_fwd_a, 8 P^2 per grid-day)
             # is evaluated inside the fused launch
-            for k, n in DAYS_PER_LAUNCH.items():
+            for k, n in days_of.items():
                 model_p2[k] += 8.0 * n
             model_p2['col_inv_a'] += 8.0
         fl = solver.fft_len
@@ -332,7 +344,9 @@ def main():
                 avg = ms / cnt
                 e = {'avg_ms': round(avg, 4), 'timed_launches': cnt,
                      'model_GBps': round(model_p2[k] * P * P / (avg * 1e-3) / 1e9, 1)}
-                b = launch_bytes(k, N, fl, direct, krows)
+                b = launch_bytes(k, N, fl, direct, krows, days_of.get(k))
+                if k in days_of:
+                    e['days_per_launch'] = round(days_of[k], 2)
                 if b:
                     e['bytes_per_launch'] = b
                     e['hbm_GBps'] = round(b / (avg * 1e-3) / 1e9, 1)
@@ -343,7 +357,7 @@ def main():
             return
         # total time per class: multi-day launches are all timed, the others every PROF_EVERY-th
         dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches']
-                  * (1 if k in DAYS_PER_LAUNCH else PROF_EVERY))
+                  * (1 if k in days_of else PROF_EVERY))
         ach = kern[dom].get('hbm_GBps')
         traffic, traffic_src = pmc_traffic(dom) if (R, K, nd) == (2048, 2049, 30) else (None, None)
         out = {
@@ -381,7 +395,7 @@ def main():
                          'survey_model_GBps': kern[dom]['model_GBps'],
                          'survey_model_frac': round(kern[dom]['model_GBps'] / HBM_PEAK_GBS, 4),
                          'bytes_per_launch': kern[dom].get('bytes_per_launch'),
-                         'days_per_launch': DAYS_PER_LAUNCH.get(dom, 1),
+                         'days_per_launch': days_of.get(dom, 1),
                          'avg_launch_ms': kern[dom]['avg_ms'],
                          'traffic_source': ('profiles/%s (committed rocprofv3 --pmc summary, not '
                                             'collected in this run)' % traffic_src) if traffic_src else None},
@@ -393,7 +407,7 @@ def main():
             # vector peak is the guide's 78.6 TFLOP/s.  Neither roof is near: see DESIGN.md 4.1c.
             import math
             ncol = fl // 2 + 1
-            flops = DAYS_PER_LAUNCH.get(dom, 1) * ncol * (2 * 5.0 * fl * math.log2(fl) + 6.0 * fl)
+            flops = days_of.get(dom, 1) * ncol * (2 * 5.0 * fl * math.log2(fl) + 6.0 * fl)
             tf = flops / (kern[dom]['avg_ms'] * 1e-3) / 1e12
             out['roofline']['fp64_valu'] = {'flops_per_launch': flops, 'achieved': round(tf, 2), 'peak': 78.6,
                                             'unit': 'TFLOP/s', 'frac': round(tf / 78.6, 4)}

@@ -112,6 +112,19 @@ def _gather_days(modelsol, days, rows, cols):
     return dict(zip(days, _gather_matrix(modelsol, days, rows, cols)))
 
 
+def _field_sums(vals, fr):
+    """[day, field] sums of the [day, field cell] values over each sentinel field's cells
+    (Bayes_funcs.py:116-144 sums the slice of every field).  A field polygon may hold no cell
+    centre at coarse rad_res: reduceat runs on the starts of the NON-empty fields only -- those are
+    strictly increasing and inside the array, and the cells between two of them are exactly one
+    field's (an empty field owns none) -- and the empty fields stay zero."""
+    out = np.zeros((vals.shape[0], len(fr['starts'])))
+    live = ~np.asarray(fr['empty'], dtype=bool)
+    if vals.shape[0] and vals.shape[1] and live.any():
+        out[:, live] = np.add.reduceat(vals, np.asarray(fr['starts'])[live], axis=1)
+    return out
+
+
 def popdensity_to_emergence(modelsol, locinfo):
     '''Expected number of wasps per release-field grid point / sentinel field whose
     oviposition results in emergence on each observation date (Bayes_funcs.py:20-152).
@@ -124,12 +137,7 @@ def popdensity_to_emergence(modelsol, locinfo):
     sentinel_emerg = []
     for fr in plan['sen']:
         vals = _gather_matrix(modelsol, fr['days'], fr['rows'], fr['cols'])         # [day, field cell]
-        if vals.shape[0] and vals.shape[1]:
-            per_day = np.add.reduceat(vals, np.minimum(fr['starts'], vals.shape[1] - 1), axis=1)
-            per_day[:, fr['empty']] = 0.0
-        else:
-            per_day = np.zeros((vals.shape[0], len(fr['starts'])))
-        sentinel_emerg.append(per_day.T @ fr['W'])
+        sentinel_emerg.append(_field_sums(vals, fr).T @ fr['W'])
     return (release_emerg, sentinel_emerg)
 
 
@@ -150,12 +158,7 @@ def expected_observations(modelsol, locinfo):
     sentinel_emerg = []
     for i, fr in enumerate(plan['sen']):
         v = blocks[nrel + i]
-        if v.shape[0] and v.shape[1]:
-            per_day = np.add.reduceat(v, np.minimum(fr['starts'], v.shape[1] - 1), axis=1)
-            per_day[:, fr['empty']] = 0.0
-        else:
-            per_day = np.zeros((v.shape[0], len(fr['starts'])))
-        sentinel_emerg.append(per_day.T @ fr['W'])
+        sentinel_emerg.append(_field_sums(v, fr).T @ fr['W'])
     g = plan['grid']
     index = {day: n for n, day in enumerate(g['udays'])}
     grid = blocks[-1][[index[day] for day in g['days']]].T.copy()

@@ -106,7 +106,7 @@ struct RowInvArgs {
   // launcher when the input does not come straight out of the Infinity Cache (full-column pipeline)
   int persistent;
   int nrec;                   // > 0: batch entry b writes rec_multi[b] (the days of a chained group)
-  double* rec_multi[8];
+  double* rec_multi[16];      // = PS_MAX_GROUP_DAYS (ps_solver.hip)
   FftProg prog;
 };
 

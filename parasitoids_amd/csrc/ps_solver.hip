@@ -141,11 +141,14 @@ static const int kPredGrid = 512;  // grid of the flag-conditional (usually empt
 // (a convolution with a pmf cannot raise the maximum of the dust it moves), so the fast chain IS
 // the exact-torus chain to <= 4 * days * kCleanEps.  FFT round-off in the pad is ~1e-18.
 static const double kCleanEps = 1e-15;
-#define PS_PROF_NCLS 13
+#define PS_PROF_NCLS 15
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
        PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6, PS_PROF_COL_INV_A2 = 7,
        PS_PROF_COL_INV_A4 = 8, PS_PROF_COL_INV_A8 = 9, PS_PROF_ROW_INV2 = 10, PS_PROF_ROW_INV4 = 11,
-       PS_PROF_ROW_INV8 = 12 };
+       PS_PROF_ROW_INV8 = 12,
+       PS_PROF_COL_INV_AN = 13,   // any other number of chained days in one launch (days counted in prof_days)
+       PS_PROF_ROW_INVN = 14 };
+#define PS_MAX_GROUP_DAYS 16       // most days one chained full-column pass / batched row pass takes
 
 struct ColPass {
   DevPlan* plan;
@@ -243,6 +246,7 @@ struct ps_solver {
   int auto_first_regime = 2;        // helper the last hand-over started with (1 wide, 2 child)
   int auto_first = -1;         // first day of the last chain_run that ran in the child (-1: none)
   int auto_hint = -1;          // the same, relative to `first`, remembered for the next run
+  int noflag_hint = 0;         // leading days of the last chain_run that raised no flag (auto: stayed clean), when it ran to its end
   long long auto_runs = 0;
   // back_solve: partial spectra of the N x N release-day filters, keyed by content.  The
   // reference calls back_solve with the same r_spread[:-1] on every simulated day
@@ -257,12 +261,13 @@ struct ps_solver {
   DevBuf<unsigned long long> fold_padmax;
   // optional per-kernel-class HIP event timing (bench.py roofline leg)
   bool prof_on = false;
-  struct ProfRec { int cls; hipEvent_t a, b; };
+  struct ProfRec { int cls; hipEvent_t a, b; int days; };
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[PS_PROF_NCLS] = {0};
   long long prof_cnt[PS_PROF_NCLS] = {0};   // sampled (timed) launches
   long long prof_seen[PS_PROF_NCLS] = {0};  // all launches
+  long long prof_days[PS_PROF_NCLS] = {0};  // grid-days of the timed launches (multi-day classes)
   int prof_every = 1;                       // time every n-th launch of a class
 };
 
@@ -280,7 +285,8 @@ struct ProfScope {
   ps_solver* s;
   ps_solver::ProfRec r;
   bool on;
-  ProfScope(ps_solver* s_, int cls) : s(s_), on(false) {
+  ProfScope(ps_solver* s_, int cls, int days = 1) : s(s_), on(false) {
+    r.days = days;
     if (!s->prof_on) return;
     // the few multi-day launches are all timed; the others every prof_every-th per class
     on = cls >= PS_PROF_COL_INV_A2 || (s->prof_seen[cls]++ % s->prof_every) == 0;
@@ -437,9 +443,9 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   RowInvArgs a;
   a.persistent = (row_inv_persistent(s) && !(s->tpipe && s->tinv && !full_field)) ? 1 : 0;
   a.nrec = 0;
-  for (int i = 0; i < 8; ++i) a.rec_multi[i] = nullptr;
+  for (int i = 0; i < PS_MAX_GROUP_DAYS; ++i) a.rec_multi[i] = nullptr;
   if (recs_multi) {
-    if (!a.persistent || batch > 8) return ps_fail(PS_ERR_STATE, "row pass: a record table needs the persistent kernel and at most 8 entries");
+    if (!a.persistent || batch > PS_MAX_GROUP_DAYS) return ps_fail(PS_ERR_STATE, "row pass: a record table needs the persistent kernel and at most %d entries", PS_MAX_GROUP_DAYS);
     a.nrec = batch;
     for (int i = 0; i < batch; ++i) a.rec_multi[i] = recs_multi[i];
   }
@@ -469,7 +475,8 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
                      4 * (thr / 64) * sizeof(double);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, !recs_multi ? PS_PROF_ROW_INV : batch == 2 ? PS_PROF_ROW_INV2 : batch == 4 ? PS_PROF_ROW_INV4
-                                : batch == 8 ? PS_PROF_ROW_INV8 : PS_PROF_ROW_INV);
+                                : batch == 8 ? PS_PROF_ROW_INV8 : batch == 1 ? PS_PROF_ROW_INV : PS_PROF_ROW_INVN,
+                 recs_multi ? batch : 1);
   if (s->rs_r2 != 0) {
     if (!rs_launch_row_inv(s->rs_r2, s->rs_r3, a, npairs, batch, s->stream))
       return ps_fail(PS_ERR_STATE, "no register-resident row kernel for 16 x %d x %d", s->rs_r2, s->rs_r3);
@@ -504,7 +511,8 @@ static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, 
   ProfScope prof(s, pred ? PS_PROF_REFFT
                           : (mode == 1 ? PS_PROF_COL_FWD_A
                                        : (nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4
-                                          : nd == 8 ? PS_PROF_COL_INV_A8 : PS_PROF_COL_INV_A)));
+                                          : nd == 8 ? PS_PROF_COL_INV_A8 : nd == 1 ? PS_PROF_COL_INV_A : PS_PROF_COL_INV_AN)),
+                 nd);
   if (!rs_launch_colfull(s->rs_r2, s->rs_r3, a, lines8, batch, s->stream))
     return ps_fail(PS_ERR_UNSUPPORTED, "full-column pass: size 16 x %d x %d cannot run this (chained days need the state column in LDS)",
                    s->rs_r2, s->rs_r3);
@@ -765,7 +773,7 @@ static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, dou
     RowLive live = s->kt_live;
     live.range = rowrange;
     PS_TRY(launch_colfull(s, 0, kt, state, 1, s->T1.p, 1, live, nullptr, nd));
-    if (row_inv_persistent(s) && !s->tinv && nd <= 8 && getenv("PS_NO_ROW_BATCH") == nullptr) {
+    if (row_inv_persistent(s) && !s->tinv && nd <= PS_MAX_GROUP_DAYS && getenv("PS_NO_ROW_BATCH") == nullptr) {
       // one launch for the rows of all nd days: nd x 2593 units over 256 persistent workgroups leave
       // 1/80 of a round idle at the end instead of 1/11 per day
       PS_TRY(launch_row_inv(s, s->T1.p, nullptr, d0, nd, negval, stat_scale, false, recs));
@@ -1247,6 +1255,17 @@ static int kernels_ready(ps_solver* s, int d) {
   return PS_OK;
 }
 
+// Before the kernel triplets, their offset / shape tables or the live-row ranges are re-allocated
+// or overwritten: everything queued that may still read them has to be done -- a previous run's
+// scatter of the later days sits on the low-priority second stream, and callers such as
+// PopModel.evaluate(want_stats=False) return from ps_chain_run without synchronising.  (The
+// main stream is ordered behind the second one at the end of every ps_chain_run.)
+static int drain_kernel_readers(ps_solver* s) {
+  if (s->stream2) PS_HIP(hipStreamSynchronize(s->stream2));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  return PS_OK;
+}
+
 // `rows`: host copy of the COO row indices, or nullptr (kernels already on the device: the
 // whole K_d box is taken as live -- prob_mass kernels are shrunk to their support)
 static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
@@ -1310,6 +1329,7 @@ extern "C" int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, co
     if (off[d + 1] < off[d]) return ps_fail(PS_ERR_BAD_ARG, "offsets not monotone");
     PS_TRY(check_coo(row + off[d], col + off[d], off[d + 1] - off[d], kshape[d], "kernel"));
   }
+  PS_TRY(drain_kernel_readers(s));
   PS_TRY(s->krow.ensure(std::max<int64_t>(tot, 1)));
   PS_TRY(s->kcol.ensure(std::max<int64_t>(tot, 1)));
   PS_TRY(s->kval.ensure(std::max<int64_t>(tot, 1)));
@@ -1326,6 +1346,7 @@ extern "C" int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, co
 int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
                                   const int* row, const int* col, const double* val) {
   const int64_t tot = off[nk];
+  PS_TRY(drain_kernel_readers(s));
   PS_TRY(s->krow.ensure(std::max<int64_t>(tot, 1)));
   PS_TRY(s->kcol.ensure(std::max<int64_t>(tot, 1)));
   PS_TRY(s->kval.ensure(std::max<int64_t>(tot, 1)));
@@ -1604,6 +1625,15 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
   }
   s->spec_window = 2;   // 2 + 4 + 8 = one chunk of 14 days, all of them in multi-day fused passes
   if (getenv("PS_NO_SPECULATION")) s->speculate = false;
+  // A solver whose previous run went through without a flag (sampler chains and ensemble members re-run
+  // the same solver on new kernels) does not feel its way 2, 4, 8, ...: it opens with windows of up to
+  // PS_MAX_GROUP_DAYS days, equal parts of the run (30 days: 15 + 15), each ONE chained full-column
+  // pass and ONE row launch.  A flag inside such a window is handled like any other (days behind
+  // it are redone); the hint is then gone.  PS_NO_WINDOW_HINT=1: A/B knob.
+  const int hint = s->noflag_hint;
+  s->noflag_hint = 0;
+  bool hinted = false;
+  int flagged_at = -1;
   // PS_MODE_AUTO: always speculate, with "clean" (nothing above kCleanEps outside the domain)
   // in the role of "no flag"; the first unclean day hands the rest of the chain to the fold path.
   // A solver whose previous run was unclean from its very first day skips the front (and looks
@@ -1648,6 +1678,11 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     set_pipeline(s, want);
   }
   PS_TRY(ensure_spectrum(s));
+  if (s->speculate && s->tpipe && colfull_chains(s) && hint >= count && count >= 4 && getenv("PS_NO_WINDOW_HINT") == nullptr) {
+    const int parts = (count + PS_MAX_GROUP_DAYS - 1) / PS_MAX_GROUP_DAYS;
+    s->spec_window = (count + parts - 1) / parts;
+    hinted = true;
+  }
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
     // Full-column pipeline, long chunk: only the kernels of the first three windows (2 + 4 + 8 days)
@@ -1655,8 +1690,8 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // run in the CUs the day passes leave idle -- a chained pass has 2593 columns for 256 CUs, its
     // eleventh round occupies 33 of them -- instead of 0.2 ms up front.
     const char* kts = getenv("PS_KT_SPLIT");                     // A/B knob (per run: tests flip it): 0 = off
-    const int split_days = kts ? atoi(kts) : 14;
-    if (s->tpipe && s->speculate && split_days > 0 && cn >= split_days + 8) {
+    const int split_days = kts ? atoi(kts) : (hinted ? s->spec_window : 14);   // = the first window(s)
+    if (s->tpipe && s->speculate && split_days > 0 && cn >= split_days + (hinted ? 4 : 8)) {
       if (!s->stream2) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = numerically greatest = lowest priority
@@ -1698,6 +1733,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // early flag wastes little.
     struct Win { int d0, w, ev; };
     std::deque<Win> q;
+    (void)flagged_at;
     int d = c0, nev = 0;
     while (true) {
       if (!s->speculate) {
@@ -1716,11 +1752,13 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
           // direct mode pairs outer indices (twice the tile): four days per pass there
           static const int direct_days = getenv("PS_DIRECT_DAYS") ? atoi(getenv("PS_DIRECT_DAYS")) : 4;   // tuning knob
           // (the full-column pipeline chains the days with the state column in registers)
-          static const int tpipe_days = getenv("PS_TPIPE_DAYS") ? atoi(getenv("PS_TPIPE_DAYS")) : 8;   // tuning knob
-          const int maxd = s->tpipe ? std::min(s->fused_days, tpipe_days)
+          static const int tpipe_days = getenv("PS_TPIPE_DAYS") ? atoi(getenv("PS_TPIPE_DAYS")) : PS_MAX_GROUP_DAYS;   // tuning knob
+          const int maxd = s->tpipe ? std::min(s->fused_days >= 8 ? PS_MAX_GROUP_DAYS : s->fused_days, tpipe_days)
                                     : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
           if (maxd > 1 && w - i >= 2) {
-            const int nd = (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
+            // the chained full-column pass takes any number of days; the tiled fused pass 2, 4 or 8
+            const int nd = s->tpipe ? std::min(maxd, w - i)
+                                    : (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
             PS_TRY(kernels_ready(s, d + i + nd - 1));
             const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
             PS_TRY(conv_inv_multi(s, B, nd, s->Ahat.p, &s->recs[PS_REC_CHAIN][d + i], d + i, negval, stat_scale,
@@ -1754,6 +1792,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       }
       if (f < 0) continue;
       q.clear();   // whatever was enqueued after day f is void; stream order keeps it harmless
+      flagged_at = f;
       if (s->auto_exact) {
         double mf;
         __builtin_memcpy(&mf, &s->hflags[f], sizeof(double));
@@ -1767,6 +1806,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       d = f + 1;
     }
   }
+  if (s->speculate && flagged_at < 0) s->noflag_hint = count;
   return PS_OK;
 }
 
@@ -2159,6 +2199,7 @@ static int prof_drain(ps_solver* s) {
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       s->prof_ms[r.cls] += ms;
       s->prof_cnt[r.cls] += 1;
+      s->prof_days[r.cls] += r.days;
     }
     s->prof_pool.push_back(r.a);
     s->prof_pool.push_back(r.b);
@@ -2171,7 +2212,7 @@ extern "C" int ps_prof_enable(ps_solver* s, int on) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(prof_drain(s));
-  for (int i = 0; i < PS_PROF_NCLS; ++i) { s->prof_ms[i] = 0; s->prof_cnt[i] = 0; s->prof_seen[i] = 0; }
+  for (int i = 0; i < PS_PROF_NCLS; ++i) { s->prof_ms[i] = 0; s->prof_cnt[i] = 0; s->prof_seen[i] = 0; s->prof_days[i] = 0; }
   s->prof_on = on != 0;
   s->prof_every = on > 1 ? on : 1;   // on = n > 1: time every n-th launch of each class
   return PS_OK;
@@ -2185,6 +2226,14 @@ extern "C" int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* c
     total_ms[i] = i < PS_PROF_NCLS ? s->prof_ms[i] : 0.0;
     count[i] = i < PS_PROF_NCLS ? s->prof_cnt[i] : 0;
   }
+  return PS_OK;
+}
+
+extern "C" int ps_prof_read_days(ps_solver* s, int ncls, int64_t* days) {
+  if (!s || !days) return ps_fail(PS_ERR_BAD_ARG, "prof_read_days: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(prof_drain(s));
+  for (int i = 0; i < ncls; ++i) days[i] = i < PS_PROF_NCLS ? s->prof_days[i] : 0;
   return PS_OK;
 }
 

@@ -8,6 +8,7 @@ missing, exactly the condition under which the reference's
 `CalcSol.get_solutions` falls back (CalcSol.py:161-172).
 """
 import ctypes as C
+import warnings
 
 import numpy as np
 from scipy import sparse
@@ -58,6 +59,16 @@ def _create_solver(lib, handle, dev, dom_len, max_shape, mode, chain_only=False)
     for m in order:
         rc = lib.ps_solver_create(C.byref(handle), dev, dom_len, max_shape, code[m])
         if rc == L.PS_OK:
+            if m == 'fast' and mode == 'auto':
+                # not silent: results are then no longer on the reference's N + K//2 torus
+                # (sub-1e-8 pad dust wraps differently: <= 1e-8 per un-flagged day)
+                info = [C.c_int32() for _ in range(4)]
+                lib.ps_solver_info(handle, *[C.byref(v) for v in info])
+                warnings.warn("HipSolve(mode='auto'): the reference pad %d cannot be planned exactly "
+                              "(prime factor > 1024 or size > 9720); falling back to the fast torus of "
+                              "size %d -- states may differ from the reference's by <= 1e-8 per un-flagged "
+                              "day near the boundary.  Pass mode='exact' to fail instead."
+                              % (dom_len + max_shape // 2, info[2].value), RuntimeWarning, stacklevel=3)
             return m
         if rc != L.PS_ERR_UNSUPPORTED:
             break
@@ -307,7 +318,7 @@ class HipSolve():
 
     PROF_CLASSES = ('row_fwd', 'col_fwd_a', 'col_fwd_b', 'col_inv_a', 'col_inv_b', 'row_inv',
                     'refft_pred', 'col_inv_a_x2', 'col_inv_a_x4', 'col_inv_a_x8',
-                    'row_inv_x2', 'row_inv_x4', 'row_inv_x8')
+                    'row_inv_x2', 'row_inv_x4', 'row_inv_x8', 'col_inv_a_xn', 'row_inv_xn')
 
     def prof_enable(self, on=True, every=1):
         '''HIP-event timing per kernel class on the solver's stream; `every` = n times only
@@ -321,6 +332,14 @@ class HipSolve():
         cnt = np.zeros(n, dtype=np.int64)
         L.check(self._lib.ps_prof_read(self._h, n, L.p_f64(ms), L.p_i64(cnt)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROF_CLASSES)}
+
+    def prof_days(self):
+        '''-> {class: grid-days covered by its timed launches} (the multi-day classes; `_xn` =
+        any number of chained days per launch)'''
+        n = len(self.PROF_CLASSES)
+        days = np.zeros(n, dtype=np.int64)
+        L.check(self._lib.ps_prof_read_days(self._h, n, L.p_i64(days)))
+        return {k: int(days[i]) for i, k in enumerate(self.PROF_CLASSES)}
 
     def get_spectrum(self):
         P = self.fft_len

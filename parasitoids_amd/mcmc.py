@@ -37,6 +37,12 @@ import numpy as np
 from scipy.special import gammaln
 
 from . import Bayes_funcs as BF
+from . import _lib
+
+# library return codes that mean "the model rejects these parameters" (ParasitoidModel.py:528-537,
+# :568-599 raise AssertionError for them; a kernel that outgrows the pad is a shape error)
+_PARAMETER_ERRORS = (_lib.PS_ERR_HPROB_BOUNDS, _lib.PS_ERR_PMF_NEGATIVE, _lib.PS_ERR_FLIGHT_PROB,
+                     _lib.PS_ERR_BAD_SHAPE, _lib.PS_ERR_EMPTY)
 
 NEG_INF = float('-inf')
 
@@ -497,7 +503,14 @@ class Sampler():
             return self._evaluate_fn(theta)
         try:
             self.pm.evaluate(*model_args(theta), ndays=self.ndays, want_stats=False)
-        except (AssertionError, ValueError, RuntimeError):
+        except (AssertionError, ValueError):
+            self.n_failed += 1
+            return None
+        except _lib.HipError as e:
+            # only the library's parameter / shape checks count as a rejected proposal; a device
+            # error (PS_ERR_HIP, out of memory, a missing state) must stop the run with its cause
+            if e.code not in _PARAMETER_ERRORS:
+                raise
             self.n_failed += 1
             return None
         return expected_observations(self.pm, self.li)

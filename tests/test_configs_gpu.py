@@ -76,7 +76,7 @@ def test_config3_benchmarked_stack_against_oracle(hip_lib, monkeypatch, pipeline
         # one column pass per day or group of chained days, and no second column sub-pass
         assert prof['col_inv_b'][1] == 0
         assert (prof['col_inv_a'][1] + 2 * prof['col_inv_a_x2'][1] + 4 * prof['col_inv_a_x4'][1]
-                + 8 * prof['col_inv_a_x8'][1]) == 30
+                + 8 * prof['col_inv_a_x8'][1] + s.prof_days()['col_inv_a_xn']) == 30
     ref, flags = _oracle_raw_chain(state, kernels, K, nd)
     assert not any(flags) and not any(x.flag for x in st)
     for d in range(nd):

@@ -262,3 +262,21 @@ def test_hbm_traffic_splits_multi_day_launches_by_bytes_written(tmp_path):
     for e, n in zip(res, (2, 4, 8)):
         assert abs(e['write_size_MB'] - (n * 200e3 + 100e3) / 1024.0) < 1e-9
         assert abs(e['fetch_corrected_MB'] - 2 * (n * 40e3 + 100e3) / 1024.0) < 1e-9
+
+
+def test_sentinel_field_sums_with_empty_fields():
+    """A sentinel field polygon may contain no cell centre (coarse rad_res): the per-field sums
+    must equal the reference's per-field slice sums (Bayes_funcs.py:116-144) wherever the empty
+    fields sit -- last, in the middle, first, several in a row."""
+    from parasitoids_amd import Bayes_funcs as BF
+    rng = np.random.default_rng(11)
+    for lens in ([3, 0], [3, 0, 2], [0, 4, 1], [2, 0, 0, 3, 0], [0, 0], [5], [1, 1, 0, 0]):
+        n = sum(lens)
+        vals = rng.random((4, n))
+        b = np.cumsum([0] + lens)
+        fr = dict(starts=b[:-1], empty=np.array([l == 0 for l in lens]))
+        want = np.array([[v[b[i]:b[i + 1]].sum() for i in range(len(lens))] for v in vals])
+        got = BF._field_sums(vals, fr)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-15, atol=0)
+    assert BF._field_sums(np.zeros((0, 3)), dict(starts=np.array([0, 2]), empty=np.array([False, False]))).shape == (0, 2)

@@ -461,6 +461,54 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
                 assert np.array_equal(a, b)
 
 
+def test_window_hint_changes_nothing(hip_lib, monkeypatch):
+    """A solver whose previous chain raised no flag opens its next run with windows of up to 16
+    days (one chained full-column pass + one row launch each: `col_inv_a_xn`, `row_inv_xn`) instead
+    of 2, 4, 8, ...  Same records, flags and statistics bit for bit -- for a clean chain re-run, and
+    for a re-run on a state that DOES raise a flag inside the first long window (the days behind
+    it are redone one at a time, the hint is gone for the run after)."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    monkeypatch.setenv('PS_RSP', '1')      # the persistent (batched) row kernel also below 1536 points
+    R, K, nd = 400, 401, 20
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+    centre = sparse.coo_matrix(([1.0], ([400], [400])), shape=(N, N))
+    edge = sparse.coo_matrix(([1.0], ([770], [770])), shape=(N, N))
+
+    def run(s, state):
+        s.set_state(state)
+        s.prof_enable(True, every=1)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        days = s.prof_days()
+        return ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st],
+                days['col_inv_a_xn'], days['row_inv_xn'])
+
+    s = hip_lib.HipSolve(centre, [K, K], mode='fast', chain_only=True)
+    assert s.fft_len == 1008 and s.full_column
+    s.set_kernels(kernels)
+    a = run(s, centre)                     # windows 2, 4, 8, 6: nothing hinted
+    assert not any(f for f, _, _, _ in a[1])
+    b = run(s, centre)                     # hinted: 10 + 10
+    assert b[2] == nd and b[3] == nd, b[2:]
+    assert a[1] == b[1]
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y)
+    c = run(s, edge)                       # hinted again, but this state flags early
+    assert any(f for f, _, _, _ in c[1])
+    s.close()
+    monkeypatch.setenv('PS_NO_WINDOW_HINT', '1')
+    monkeypatch.setenv('PS_NO_SPECULATION', '1')
+    s2 = hip_lib.HipSolve(edge, [K, K], mode='fast', chain_only=True)
+    s2.set_kernels(kernels)
+    d = run(s2, edge)
+    s2.close()
+    assert c[1] == d[1]
+    for x, y in zip(c[0], d[0]):
+        assert np.array_equal(x, y)
+
+
 def test_second_stream_kernel_transforms_change_nothing(hip_lib, monkeypatch):
     """Long chunks in the full-column pipeline transform only the kernels of the first windows
     ahead of the day passes; the rest run on a second stream behind them (ps_chain_run, PS_KT_SPLIT).
