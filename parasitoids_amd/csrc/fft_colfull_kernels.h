@@ -330,3 +330,240 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
     }
   }
 }
+
+
+// ------------------------------------------------------------------ chained days, two roles
+// What bounds the chained pass above, measured without HBM in the loop (scripts/microbench/
+// fftcore.hip, 5184): a day step costs 11.7 us on the CU = 7.3 us of butterflies + 3.5 us of LDS
+// exchange + barriers, and they ADD UP -- six waves sit 2-2-1-1 on the four SIMDs (wave slots are
+// handed out round-robin from SIMD 0, which is also why a second 6-wave workgroup is never
+// co-resident above 128 registers), so the VALU time is that of TWO waves per stage, and everybody
+// is in the same phase.  Two transforms side by side in one 12-wave workgroup (3-2-3-2 instead of
+// twice 2-2-1-1, twice the waves to hide LDS latency) take 8.8 us.
+//
+// The two transforms of a chained day step that CAN run side by side are the inverse of day d's
+// product and the forward transform of day d+1's kernel column.  So the workgroup has two roles
+// of NTHR threads each, in lockstep (shared barriers, all at top level):
+//   role 0 ("A"): slot s >= 1: product of day s-1 out of the LDS state column (first-stage input
+//                 order) -> inverse transform -> the row-major intermediate of day s-1
+//   role 1 ("B"): slot s < nd: kernel column of day s -> forward transform -> state column *= it
+// nd + 1 slots for nd days (A idles in the first, B in the last: the state column is loaded /
+// stored there), which is why only long groups come here (a solver whose previous run raised no
+// flag opens with windows of up to 16 days).  Same butterflies, twiddles and products in the same
+// order as the single-role pass: results are bit-identical.
+//
+// LDS: the state column (16 L bytes) leaves no room for two whole exchange buffers (8.5 L each),
+// so each role's exchange runs in two half passes through a half-size buffer (the writers of the
+// first half are the threads below a split, the readers' first half the inputs q < ceil(R/2); 15
+// barriers per transform instead of 8 -- measured +5 %).  What is left (32 KB at 5184) stages the
+// NEXT day's kernel column, copied HBM -> LDS by the load unit (global_load_lds_dwordx4) while this
+// slot's transforms run: role B has no registers to spare for a prefetch (the whole kernel sits at
+// the 168 registers a 12-wave workgroup may use), and a fetch at the top of the slot would stall
+// both roles.  Live rows beyond the staging capacity are loaded directly.
+template <int R1, int R2, int R3>
+struct RsDual {
+  using S = Rs<R1, R2, R3>;
+  static constexpr int L = S::L;
+  static constexpr int QA2 = (R2 + 1) / 2, QA3 = (R3 + 1) / 2;
+  static constexpr int IA = QA2 * S::T2, IB = QA3 * S::T3;          // elements of the first half pass (exchange 1, 2)
+  static constexpr int JA1 = IA / 16, JA2 = 16 * QA3;               // its writer threads: j < JA
+  static constexpr int OFF1 = IA + IA / 16, OFF2 = IB + IB / 16;    // padded words ahead of the second half
+  static constexpr int mx(int a, int b) { return a > b ? a : b; }
+  static constexpr int MAXEL = mx(mx(IA, L - IA), mx(IB, L - IB));
+  static constexpr int XH = (MAXEL + MAXEL / 16 + 32 + 15) & ~15;   // doubles per role
+  static constexpr size_t fixed_bytes = 2 * (size_t)XH * sizeof(double) + (size_t)L * sizeof(cplx);
+  static constexpr long spare = (long)160 * 1024 - (long)fixed_bytes;
+  static constexpr int CAP = spare > 0 ? (int)(spare / (64 * (long)sizeof(cplx))) * 64 : 0;   // staged elements: whole 1 KB chunks
+  // (radix 21 and up: the butterflies do not fit the 168 registers of a 12-wave workgroup without scratch)
+  static constexpr bool ok = S::NTHR <= 384 && CAP >= 512 && S::RMAX <= 20;
+  static constexpr size_t bytes = fixed_bytes + (size_t)CAP * sizeof(cplx);
+  static_assert(S::T2 % 16 == 0 && S::T3 % 16 == 0, "half-pass offsets assume whole padding groups");
+};
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(ColFullArgs a) {
+  using S = Rs<R1, R2, R3>;
+  using D = RsDual<R1, R2, R3>;
+  constexpr int L = S::L;
+  constexpr int NW = S::NTHR / 64;
+  if (pred_skip(a.pred)) return;
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);   // see k_colfull
+  if (c >= a.ncols) return;
+  const int role = threadIdx.x / S::NTHR;                      // wave-uniform
+  const int j0 = threadIdx.x - role * S::NTHR;
+  double* exh = reinterpret_cast<double*>(ps_lds_raw) + role * D::XH;
+  cplx* sst = reinterpret_cast<cplx*>(reinterpret_cast<double*>(ps_lds_raw) + 2 * D::XH);
+  cplx* stage = sst + L;
+  const FftProg& P = a.prog;
+  const cplx w2c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j0));
+  const cplx w3c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j0 < S::T3 ? S::tw3(j0) : 0);
+  cplx* st = a.state + (int64_t)blockIdx.y * a.state_bstride + (int64_t)c * L;
+  const int nd = a.nd;
+  const int lane = j0 & 63, wave = j0 >> 6;
+
+  // live rows of day `day`'s kernel column: two torus intervals [a1, b1) and [a2, b2) (RowLive:
+  // the two pieces of the source map, clipped to the day's source-row range)
+  auto live_of = [&](int day, int& a1, int& b1, int& a2, int& b2) {
+    if (!a.live.on) { a1 = 0; b1 = L; a2 = L; b2 = L; return; }
+    int lo = 0, hi = 0x3fffffff;
+    if (a.live.range) { lo = a.live.range[2 * ((int)blockIdx.y + day)]; hi = a.live.range[2 * ((int)blockIdx.y + day) + 1]; }
+    const SrcMap& m = a.live.map;
+    a1 = max(0, lo - m.off1); b1 = min(m.n1, hi - m.off1 + 1);
+    a2 = m.lo2 + max(0, lo - m.off2); b2 = min(L, m.lo2 + hi - m.off2 + 1);
+    if (b1 < a1) b1 = a1;
+    if (b2 < a2) b2 = a2;
+    if (a2 < b1) a2 = b1;      // (maps of this code never overlap; keeps the staging order well defined)
+  };
+  // role B: copy the live rows of day `day`'s kernel column into the staging area, row order,
+  // 1 KB per instruction; every wave takes the chunks wave, wave + NW, ...
+  auto stage_column = [&](int day) {
+    int a1, b1, a2, b2;
+    live_of(day, a1, b1, a2, b2);
+    const int len1 = b1 - a1, tot = min(len1 + (b2 - a2), D::CAP);
+    const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)day * a.src_dstride + (int64_t)c * L;
+    for (int ch = wave; ch * 64 < tot; ch += NW) {
+      int e = ch * 64 + lane;
+      e = e < tot ? e : tot - 1;                       // the last chunk: stay inside the live rows
+      const int n = e < len1 ? a1 + e : a2 + (e - len1);
+      __builtin_amdgcn_global_load_lds(sc + n, (ps_lds_ptr)(stage + ch * 64), 16, 0, 0);
+    }
+  };
+
+  // prologue: state column -> LDS (role A, coalesced), kernel column of day 0 -> staging (role B)
+  if (role == 0) {
+#pragma unroll 7
+    for (int k = j0; k < L; k += S::NTHR) sst[k] = st[k];
+  } else {
+    stage_column(0);
+    PS_WAIT_VM0();
+  }
+  PS_BAR_LDS();
+
+  for (int slot = 0; slot <= nd; ++slot) {
+    const bool act = role == 0 ? slot >= 1 : slot < nd;        // wave-uniform
+    cplx x[S::RMAX];
+    int j = j0;
+    cplx w2 = w2c, w3 = w3c;
+    // opaque per-slot copies (see k_colfull): no loop-invariant twiddle powers or addresses in registers
+    asm volatile("" : "+v"(j), "+v"(w2.x), "+v"(w2.y), "+v"(w3.x), "+v"(w3.y));
+    // ---- first-stage inputs.  Role A's inverse transform runs through the FORWARD code on
+    // conjugated data (inverse(x) == conj(forward(conj(x))) bit for bit, see rs_stage): one
+    // transform body for both roles, one set of data registers.
+    if (act && j < S::T1) {
+      if (role == 0) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) x[q] = cconj(sst[j + q * S::T1]);
+      } else {
+        int a1, b1, a2, b2;
+        live_of(slot, a1, b1, a2, b2);
+        const int len1 = b1 - a1;
+        const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)slot * a.src_dstride + (int64_t)c * L;
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+          const int n = j + q * S::T1;
+          x[q] = make_double2(0.0, 0.0);
+          int e = -1;
+          if (n >= a1 && n < b1) e = n - a1;
+          else if (n >= a2 && n < b2) e = len1 + (n - a2);
+          if (e >= 0) x[q] = e < D::CAP ? stage[e] : sc[n];
+        }
+      }
+      bfly<R1, PS_FWD>(x);
+    }
+    // ---- exchange 1 in two half passes per part.  A thread of the second half pass still holds
+    // un-written outputs when the first half's inputs arrive: those wait in `keep` until its put.
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      double keep[D::QA2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (act && j < S::T1 && (j < D::JA1) == (h == 0)) {
+          if (part) rs_put<R1, 1>(exh, S::x1_w(j) - h * D::OFF1, 1, x);
+          else rs_put<R1, 0>(exh, S::x1_w(j) - h * D::OFF1, 1, x);
+        }
+        PS_BAR_LDS();
+        if (part == 0 && h == 0 && role == 1 && slot + 1 < nd) stage_column(slot + 1);   // the staging area was read above
+        if (act && j < S::T2) {
+          if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < D::QA2; ++q) keep[q] = exh[S::x_r(j) + q * S::X1_RS];
+          } else {
+#pragma unroll
+            for (int q = D::QA2; q < R2; ++q) {
+              const double v = exh[S::x_r(j) + q * S::X1_RS - D::OFF1];
+              if (part) x[q].y = v;
+              else x[q].x = v;
+            }
+#pragma unroll
+            for (int q = 0; q < D::QA2; ++q) {
+              if (part) x[q].y = keep[q];
+              else x[q].x = keep[q];
+            }
+          }
+        }
+        if (!(part == 1 && h == 1)) PS_BAR_LDS();
+      }
+    }
+    // (twiddle powers are formed here, not hoisted above the exchange where they would cost 36 registers)
+    asm volatile("" : "+v"(w2.x), "+v"(w2.y));
+    if (act && j < S::T2) rs_stage<R2, PS_FWD>(x, w2, true);
+    PS_BAR_LDS();
+    // ---- exchange 2
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      double keep[D::QA3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (act && j < S::T2 && (j < D::JA2) == (h == 0)) {
+          if (part) rs_put<R2, 1>(exh, S::x2_w(j) - h * D::OFF2, 17, x);
+          else rs_put<R2, 0>(exh, S::x2_w(j) - h * D::OFF2, 17, x);
+        }
+        PS_BAR_LDS();
+        if (act && j < S::T3) {
+          if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < D::QA3; ++q) keep[q] = exh[S::x_r(j) + q * S::X2_RS];
+          } else {
+#pragma unroll
+            for (int q = D::QA3; q < R3; ++q) {
+              const double v = exh[S::x_r(j) + q * S::X2_RS - D::OFF2];
+              if (part) x[q].y = v;
+              else x[q].x = v;
+            }
+#pragma unroll
+            for (int q = 0; q < D::QA3; ++q) {
+              if (part) x[q].y = keep[q];
+              else x[q].x = keep[q];
+            }
+          }
+        }
+        if (!(part == 1 && h == 1)) PS_BAR_LDS();
+      }
+    }
+    asm volatile("" : "+v"(w3.x), "+v"(w3.y));
+    if (act && j < S::T3) rs_stage<R3, PS_FWD>(x, w3, true);
+    if (act && j < S::T3) {
+      if (role == 0) {                                     // conj: spatial rows j + q T3 of day slot - 1
+        cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)(slot - 1) * a.dst_dstride +
+                  (a.dst_t ? (int64_t)c * L : (int64_t)c);
+        const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
+#pragma unroll
+        for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = cconj(x[q]);
+      } else {                                             // X[j + q T3] of day slot's kernel column
+#pragma unroll
+        for (int q = 0; q < R3; ++q) {
+          const cplx p = cmul(sst[j + q * S::T3], x[q]);   // CalcSol.py:66
+          sst[j + q * S::T3] = p;
+        }
+      }
+    }
+    // the idle role of the last slot writes the final state back (it is complete since the end of
+    // slot nd - 1) while role A runs the last inverse transform
+    if (role == 1 && slot == nd && a.store_prod) {
+      for (int k = j; k < L; k += S::NTHR) st[k] = sst[k];
+    }
+    if (role == 1) PS_WAIT_VM0();                          // this wave's share of the next kernel column has landed
+    PS_BAR_LDS();                                          // product and staging visible; exchange buffers free
+  }
+}

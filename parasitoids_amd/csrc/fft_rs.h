@@ -83,7 +83,11 @@ PS_HD void rs_stage(cplx* x, cplx w1, bool tw) {
     for (int q = 1; q < R; ++q) {
       const int a = q >> 2, b = q & 3;
       const cplx w = a == 0 ? lo[b] : (b == 0 ? hi[a] : cmul(hi[a], lo[b]));
-      x[q] = DIR == PS_FWD ? cmul(x[q], w) : cmulc(x[q], w);
+      // inverse: x * conj(w) written as cmul with the conjugated twiddle (not cmulc): every
+      // multiply-add then rounds like the forward transform's on conjugated data, so
+      // inverse(x) == conj(forward(conj(x))) BIT FOR BIT -- the two-role chained pass
+      // (k_colfull_dual) runs its inverse transforms through the forward code that way
+      x[q] = DIR == PS_FWD ? cmul(x[q], w) : cmul(x[q], cconj(w));
     }
   }
   bfly<R, DIR>(x);

@@ -340,7 +340,7 @@ static int set_lds_attr() {
                       PS_MULTI_K(1), PS_MULTI_K(2), PS_MULTI_K(4), PS_MULTI_K(8)};
 #undef PS_MULTI_K
   for (const void* k : ks) PS_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-  if (rs_rows_set_attrs() != 0 || rs_colfull_set_attrs() != 0) return ps_fail(PS_ERR_HIP, "hipFuncSetAttribute failed for a register-resident kernel");
+  if (rs_rows_set_attrs() != 0 || rs_colfull_set_attrs() != 0 || rs_coldual_set_attrs() != 0) return ps_fail(PS_ERR_HIP, "hipFuncSetAttribute failed for a register-resident kernel");
   done = true;
   return PS_OK;
 }
@@ -513,6 +513,15 @@ static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, 
                                        : (nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4
                                           : nd == 8 ? PS_PROF_COL_INV_A8 : nd == 1 ? PS_PROF_COL_INV_A : PS_PROF_COL_INV_AN)),
                  nd);
+  // long chained groups: the two-role pass (inverse of day d next to the forward transform of day
+  // d + 1 in one 12-wave workgroup; nd + 1 slots for nd days, so it pays from ~6 days on)
+  static const int dual_min = getenv("PS_DUAL_MIN_DAYS") ? atoi(getenv("PS_DUAL_MIN_DAYS")) : 6;   // A/B knob; 0 = never
+  if (mode == 0 && !pred && store_prod && dual_min > 0 && nd >= dual_min && rs_dual_ok(s->rs_r2, s->rs_r3)) {
+    if (!rs_launch_coldual(s->rs_r2, s->rs_r3, a, lines8, batch, s->stream))
+      return ps_fail(PS_ERR_STATE, "two-role full-column pass: size 16 x %d x %d is not served", s->rs_r2, s->rs_r3);
+    PS_HIP(hipGetLastError());
+    return PS_OK;
+  }
   if (!rs_launch_colfull(s->rs_r2, s->rs_r3, a, lines8, batch, s->stream))
     return ps_fail(PS_ERR_UNSUPPORTED, "full-column pass: size 16 x %d x %d cannot run this (chained days need the state column in LDS)",
                    s->rs_r2, s->rs_r3);
