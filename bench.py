@@ -40,7 +40,7 @@ MODEL_P2 = {
     'row_fwd': 16.0, 'col_fwd_a': 8.0, 'col_fwd_b': 8.0, 'col_inv_a': 40.0, 'col_inv_b': 8.0,
     'row_inv': 24.0, 'refft_pred': 0.0,
     'col_inv_a_x2': 80.0, 'col_inv_a_x4': 160.0, 'col_inv_a_x8': 320.0,
-    'row_inv_x2': 48.0, 'row_inv_x4': 96.0, 'row_inv_x8': 192.0,
+    'row_inv_x2': 48.0, 'row_inv_x4': 96.0, 'row_inv_x8': 192.0, 'col_tail': 0.0,
 }
 DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8,
                    'row_inv_x2': 2, 'row_inv_x4': 4, 'row_inv_x8': 8}

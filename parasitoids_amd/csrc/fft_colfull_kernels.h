@@ -49,8 +49,31 @@ struct ColFullArgs {
   int64_t src_dstride, dst_dstride;   // per day
   RowLive live;          // rows of src that were never written (known zero); range advances 2 ints per day
   const unsigned long long* pred;
+  // k_colfull_dual: sum of |x|^2 over the pad-only spatial rows (r >= pad_row0) of this column's
+  // intermediate, per day: pad_energy[(blockIdx.y + day) * ncols + c]; nullptr = not wanted
+  double* pad_energy;
+  int pad_row0, ncols_total;
+  int col0;              // first column of this launch (blocks map to columns col0, col0 + 1, ...)
   FftProg prog;          // the length-L row plan (its two-level twiddle table)
 };
+
+// One block per day: total pad-row energy of the day's intermediate (fixed summation order) ->
+// quiet[day] = 1 when even the total passes the per-pair Parseval test of the inverse row pass
+// (k_row_inv_rs: sqrt(2 P e) * scale < pad_floor), i.e. every pad-only row pair would be skipped.
+static __global__ void k_pad_quiet(const double* energy, int ncols, double P, double scale, double pad_floor, int* quiet) {
+  __shared__ double red[256];
+  const double* e = energy + (int64_t)blockIdx.x * ncols;
+  double acc = 0.0;
+  for (int c = threadIdx.x; c < ncols; c += 256) acc += e[c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  // NaN-safe: anything that is not provably quiet is read
+  if (threadIdx.x == 0) quiet[blockIdx.x] = (sqrt(2.0 * P * red[0]) * scale < pad_floor) ? 1 : 0;
+}
 
 // Single day step (mode 0 with nd == 1), the state column straight from HBM: the form the
 // compiler turns into 162 registers and no scratch (255 us per day at L = 5184).  The templated
@@ -64,7 +87,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
   // block -> column: blocks b, b+8, ..., b+56 (one XCD, dispatched back to back) own the eight
   // columns of one 128-byte line of the row-major output
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
-  const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
+  const int c = a.col0 + ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
   if (c >= a.ncols) return;   // whole workgroup: no barrier is pending
   // CEX: complex exchange words (rs_tail_c: 3 barriers per transform, 8 for the whole day step
   // instead of 21); the buffer is then 17 L bytes, which sizes beyond 9400 do not have
@@ -175,7 +198,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
   // block -> column: blocks b, b+8, ..., b+56 (one XCD, dispatched back to back) own the eight
   // columns of one 128-byte line of the row-major output
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
-  const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
+  const int c = a.col0 + ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);
   if (c >= a.ncols) return;   // whole workgroup: no barrier is pending
   double* ex = reinterpret_cast<double*>(ps_lds_raw);
   cplx* sst = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);   // CHAIN: the state column, [L]
@@ -197,6 +220,26 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
       const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
 #pragma unroll
       for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = x[q];
+    }
+    if (a.pad_energy) {   // as k_colfull_dual: |x|^2 over the pad-only rows of this column and day
+      double pe = 0.0;
+      if (j < S::T3) {
+        const int qlo = a.pad_row0 / S::T3;
+#pragma unroll
+        for (int q = 0; q < R3; ++q) {
+          if (q < qlo) continue;
+          if (q > qlo || j + q * S::T3 >= a.pad_row0) pe += x[q].x * x[q].x + x[q].y * x[q].y;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) pe += __shfl_down(pe, off);
+      double* red = ex + Y::XW;
+      if ((j & 63) == 0) red[j >> 6] = pe;
+      __syncthreads();
+      if (j == 0) {
+        double e = 0.0;
+        for (int w = 0; w < S::NTHR / 64; ++w) e += red[w];
+        a.pad_energy[(int64_t)blockIdx.y * a.ncols_total + c] = e;
+      }
     }
   } else if constexpr (MODE == 1) {    // forward: row-pass output column -> state column
     cplx x[S::RMAX];
@@ -332,6 +375,25 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
 }
 
 
+// Chained days of a FEW columns, spread over the chip: the spectra K_d of their kernel columns are
+// already in `khat` ([day][column][L], written by the forward pass, mode 1); every element runs
+// the chain A_{d+1} = A_d K_d (CalcSol.py:66; the same products in the same order as the chained
+// passes), leaves the products in place of the spectra (the inverse pass, mode 2, reads them) and
+// the last one in the state.  See conv_inv_multi: the columns that would make a thin extra round
+// of the chained pass (2593 columns = 10 rounds of 256 CUs + 33).
+static __global__ void k_prefix_cols(cplx* state, cplx* khat, int L, int ncols, int nd) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= L) return;
+  const int64_t col = (int64_t)blockIdx.y * L + k;
+  cplx p = state[col];
+  for (int d = 0; d < nd; ++d) {
+    cplx* e = khat + ((int64_t)d * ncols) * L + col;
+    p = cmul(p, *e);
+    *e = p;
+  }
+  state[col] = p;
+}
+
 // ------------------------------------------------------------------ chained days, two roles
 // What bounds the chained pass above, measured without HBM in the loop (scripts/microbench/
 // fftcore.hip, 5184): a day step costs 11.7 us on the CU = 7.3 us of butterflies + 3.5 us of LDS
@@ -370,12 +432,13 @@ struct RsDual {
   static constexpr int OFF1 = IA + IA / 16, OFF2 = IB + IB / 16;    // padded words ahead of the second half
   static constexpr int mx(int a, int b) { return a > b ? a : b; }
   static constexpr int MAXEL = mx(mx(IA, L - IA), mx(IB, L - IB));
-  static constexpr int XH = (MAXEL + MAXEL / 16 + 32 + 15) & ~15;   // doubles per role
+  static constexpr int XH = (MAXEL + MAXEL / 16 + 32 + 15) & ~15;   // doubles per role (>= 32 slack words at the end: wave sums)
   static constexpr size_t fixed_bytes = 2 * (size_t)XH * sizeof(double) + (size_t)L * sizeof(cplx);
   static constexpr long spare = (long)160 * 1024 - (long)fixed_bytes;
   static constexpr int CAP = spare > 0 ? (int)(spare / (64 * (long)sizeof(cplx))) * 64 : 0;   // staged elements: whole 1 KB chunks
-  // (radix 21 and up: the butterflies do not fit the 168 registers of a 12-wave workgroup without scratch)
-  static constexpr bool ok = S::NTHR <= 384 && CAP >= 512 && S::RMAX <= 20;
+  // (radix 20 and up: the butterflies do not fit the 168 registers of a 12-wave workgroup without scratch --
+  // a few spilled registers cost more than the second role gains, measured)
+  static constexpr bool ok = S::NTHR <= 384 && CAP >= 512 && S::RMAX <= 18;   // (<= 6 waves per role: their sums fit the slack words)
   static constexpr size_t bytes = fixed_bytes + (size_t)CAP * sizeof(cplx);
   static_assert(S::T2 % 16 == 0 && S::T3 % 16 == 0, "half-pass offsets assume whole padding groups");
 };
@@ -388,7 +451,7 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
   constexpr int NW = S::NTHR / 64;
   if (pred_skip(a.pred)) return;
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
-  const int c = ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);   // see k_colfull
+  const int c = a.col0 + ((((qq >> 3) << 3) + xcd) << 3) + (qq & 7);   // see k_colfull
   if (c >= a.ncols) return;
   const int role = threadIdx.x / S::NTHR;                      // wave-uniform
   const int j0 = threadIdx.x - role * S::NTHR;
@@ -563,7 +626,25 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
     if (role == 1 && slot == nd && a.store_prod) {
       for (int k = j; k < L; k += S::NTHR) st[k] = sst[k];
     }
+    if (role == 0 && a.pad_energy) {                       // wave sums -> the slack words behind role A's exchange buffer
+      double pe = 0.0;                                     // (after the stores: x is all that is live here)
+      if (act && j < S::T3) {
+        const int qlo = a.pad_row0 / S::T3;                // uniform: only the last few q hold pad-only rows
+#pragma unroll
+        for (int q = 0; q < R3; ++q) {
+          if (q < qlo) continue;
+          if (q > qlo || j + q * S::T3 >= a.pad_row0) pe += x[q].x * x[q].x + x[q].y * x[q].y;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) pe += __shfl_down(pe, off);
+      if (lane == 0) exh[D::XH - 8 + wave] = pe;
+    }
     if (role == 1) PS_WAIT_VM0();                          // this wave's share of the next kernel column has landed
     PS_BAR_LDS();                                          // product and staging visible; exchange buffers free
+    if (role == 0 && a.pad_energy && slot >= 1 && j0 == 0) {
+      double e = 0.0;
+      for (int w = 0; w < NW; ++w) e += exh[D::XH - 8 + w];
+      a.pad_energy[((int64_t)blockIdx.y + (slot - 1)) * a.ncols_total + c] = e;
+    }
   }
 }

@@ -105,6 +105,10 @@ struct RowInvArgs {
   // k_row_inv_rsp (persistent, prefetching; register-resident sizes up to 6400): chosen by the
   // launcher when the input does not come straight out of the Infinity Cache (full-column pipeline)
   int persistent;
+  // per batch entry: 1 = the column pass found the pad-only row pairs of this day too quiet to raise
+  // the flag (k_pad_quiet: the sum of the per-pair Parseval tests below) -- k_row_inv_rsp then neither
+  // fetches nor tests them; nullptr = unknown
+  const int* pad_quiet;
   int nrec;                   // > 0: batch entry b writes rec_multi[b] (the days of a chained group)
   double* rec_multi[16];      // = PS_MAX_GROUP_DAYS (ps_solver.hip)
   FftProg prog;

@@ -229,6 +229,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
   // rows of unit u -> staging; every wave copies the chunks c = wave, wave + NW, ... (row A, then B)
   auto prefetch = [&](int u) {
     const int b = u / npairs, pair = u - b * npairs;
+    if (a.pad_quiet && 2 * pair >= a.N && a.pad_quiet[b]) return;   // never read: see the round below
     const cplx* src = a.src + (int64_t)b * a.src_bstride;
     const int ra = 2 * pair, rb = (ra + 1 < a.P) ? ra + 1 : ra;
     const cplx* pa = src + (int64_t)ra * a.ld;
@@ -256,6 +257,15 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
     const int ra = 2 * pair, rb = ra + 1;
     const bool hasb = rb < a.P;
     const bool pad_only = ra >= a.N;
+    if (pad_only && a.pad_quiet && a.pad_quiet[b]) {   // uniform per workgroup
+      // The column pass summed |x|^2 over ALL pad-only rows of this day and found even that total
+      // below what one pair needs to reach pad_floor: every pair's own Parseval test (below) would
+      // skip it.  Nothing was prefetched for it; only the next unit's prefetch has to be started.
+      // (no barrier: the staging area was released by the previous round's second barrier)
+      if (u + (int)gridDim.x < units) prefetch(u + (int)gridDim.x);
+      PS_WAIT_VM0();
+      continue;
+    }
     // opaque per-round copies: nothing derived from the thread index or the stage twiddles is
     // loop-invariant for the compiler, which would otherwise hoist ~100 registers of twiddle
     // powers and LDS addresses out of the loop (and spill)

@@ -141,13 +141,14 @@ static const int kPredGrid = 512;  // grid of the flag-conditional (usually empt
 // (a convolution with a pmf cannot raise the maximum of the dust it moves), so the fast chain IS
 // the exact-torus chain to <= 4 * days * kCleanEps.  FFT round-off in the pad is ~1e-18.
 static const double kCleanEps = 1e-15;
-#define PS_PROF_NCLS 15
+#define PS_PROF_NCLS 16
 enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PROF_COL_INV_A = 3,
        PS_PROF_COL_INV_B = 4, PS_PROF_ROW_INV = 5, PS_PROF_REFFT = 6, PS_PROF_COL_INV_A2 = 7,
        PS_PROF_COL_INV_A4 = 8, PS_PROF_COL_INV_A8 = 9, PS_PROF_ROW_INV2 = 10, PS_PROF_ROW_INV4 = 11,
        PS_PROF_ROW_INV8 = 12,
        PS_PROF_COL_INV_AN = 13,   // any other number of chained days in one launch (days counted in prof_days)
-       PS_PROF_ROW_INVN = 14 };
+       PS_PROF_ROW_INVN = 14,
+       PS_PROF_COL_TAIL = 15 };   // the three launches for the columns taken out of a chained pass (conv_inv_multi)
 #define PS_MAX_GROUP_DAYS 16       // most days one chained full-column pass / batched row pass takes
 
 struct ColPass {
@@ -259,6 +260,12 @@ struct ps_solver {
   DevBuf<double> torus, lin, fold_rowsum;
   DevBuf<long long> fold_rowcnt;
   DevBuf<unsigned long long> fold_padmax;
+  // two-role chained pass -> batched row pass: per (day, column) energy of the pad-only rows of the
+  // intermediate, and the per-day verdict "no pad-only row pair can raise the flag" (k_pad_quiet)
+  DevBuf<double> pad_energy;
+  DevBuf<int> pad_quiet;
+  DevBuf<cplx> tail_hat;       // [day][column][Pf]: kernel spectra / chained products of the columns taken out of a chained pass
+  int ncu = 0;                 // compute units of the device
   // optional per-kernel-class HIP event timing (bench.py roofline leg)
   bool prof_on = false;
   struct ProfRec { int cls; hipEvent_t a, b; int days; };
@@ -439,8 +446,9 @@ static bool row_inv_persistent(const ps_solver* s) {
 // needs row_inv_persistent(s) and batch <= 8)
 static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_slot, int batch,
                           double negval, double stat_scale, bool full_field = false,
-                          double* const* recs_multi = nullptr) {
+                          double* const* recs_multi = nullptr, const int* pad_quiet = nullptr) {
   RowInvArgs a;
+  a.pad_quiet = pad_quiet;
   a.persistent = (row_inv_persistent(s) && !(s->tpipe && s->tinv && !full_field)) ? 1 : 0;
   a.nrec = 0;
   for (int i = 0; i < PS_MAX_GROUP_DAYS; ++i) a.rec_multi[i] = nullptr;
@@ -493,30 +501,48 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
 // forward 2-D transform of `batch` real sources into `out`
 // one full-column pass (k_colfull): mode 0 day step (kernel -> x state -> inverse -> dst), 1 forward
 // (src -> state), 2 inverse (state -> dst), 3 product only (state *= FFT(src))
+// does a mode-0 launch of nd days go to the two-role chained pass?
+static bool colfull_dual(const ps_solver* s, int nd) {
+  const char* e = getenv("PS_DUAL_MIN_DAYS");   // A/B knob, read per launch (tests flip it); 0 = never
+  const int dual_min = e ? atoi(e) : 6;
+  return dual_min > 0 && nd >= dual_min && rs_dual_ok(s->rs_r2, s->rs_r3);
+}
+
+// col0 / ncols: the launch covers columns [col0, ncols) (default: all H); state_bstride / dst_bstride
+// override the per-batch-entry strides (default: one spectrum)
 static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, int store_prod, cplx* dst, int batch,
-                          RowLive live, const unsigned long long* pred, int nd = 1) {
+                          RowLive live, const unsigned long long* pred, int nd = 1, double* pad_energy = nullptr,
+                          int col0 = 0, int ncols = -1, int64_t state_bstride = -1, bool timed = true) {
   ColFullArgs a;
+  a.pad_energy = nullptr;
+  a.pad_row0 = 2 * ((s->N + 1) / 2);   // first row of the first pad-only row pair
+  a.ncols_total = s->H;
+  a.col0 = col0;
   const int64_t spec = (int64_t)s->Pf * s->ld;   // T-layout arrays ([H][Pf]) fit the row-major allocation ([Pf][ld])
   a.src = src; a.src_bstride = spec;
-  a.state = state; a.state_bstride = spec;
+  a.state = state; a.state_bstride = state_bstride >= 0 ? state_bstride : spec;
   a.dst = dst; a.dst_bstride = spec;
-  a.ld = s->ld; a.ncols = s->H; a.mode = mode; a.store_prod = store_prod;
+  a.ld = s->ld; a.ncols = ncols >= 0 ? ncols : s->H; a.mode = mode; a.store_prod = store_prod;
   a.nd = nd; a.src_dstride = spec; a.dst_dstride = spec;
   a.dst_t = s->tinv ? 1 : 0;
   a.live = live;
   a.pred = pred;
   a.prog = s->row_plan.prog;
-  const int groups = (s->H + 7) / 8;       // 128-byte lines of the row-major output
-  const int lines8 = (groups + 7) / 8;     // per XCD
+  const int groups = (a.ncols - col0 + 7) / 8;   // 128-byte lines of the row-major output
+  const int lines8 = (groups + 7) / 8;           // per XCD
+  if (mode == 2) a.pad_energy = pad_energy;
+  const bool prof_was = s->prof_on;
+  if (!timed) s->prof_on = false;   // part of a scope of the caller's
   ProfScope prof(s, pred ? PS_PROF_REFFT
                           : (mode == 1 ? PS_PROF_COL_FWD_A
                                        : (nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4
                                           : nd == 8 ? PS_PROF_COL_INV_A8 : nd == 1 ? PS_PROF_COL_INV_A : PS_PROF_COL_INV_AN)),
                  nd);
+  s->prof_on = prof_was;
   // long chained groups: the two-role pass (inverse of day d next to the forward transform of day
   // d + 1 in one 12-wave workgroup; nd + 1 slots for nd days, so it pays from ~6 days on)
-  static const int dual_min = getenv("PS_DUAL_MIN_DAYS") ? atoi(getenv("PS_DUAL_MIN_DAYS")) : 6;   // A/B knob; 0 = never
-  if (mode == 0 && !pred && store_prod && dual_min > 0 && nd >= dual_min && rs_dual_ok(s->rs_r2, s->rs_r3)) {
+  if (mode == 0 && !pred && store_prod && colfull_dual(s, nd)) {
+    a.pad_energy = pad_energy;
     if (!rs_launch_coldual(s->rs_r2, s->rs_r3, a, lines8, batch, s->stream))
       return ps_fail(PS_ERR_STATE, "two-role full-column pass: size 16 x %d x %d is not served", s->rs_r2, s->rs_r3);
     PS_HIP(hipGetLastError());
@@ -781,11 +807,56 @@ static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, dou
     if (!colfull_chains(s)) return PS_OK;
     RowLive live = s->kt_live;
     live.range = rowrange;
-    PS_TRY(launch_colfull(s, 0, kt, state, 1, s->T1.p, 1, live, nullptr, nd));
-    if (row_inv_persistent(s) && !s->tinv && nd <= PS_MAX_GROUP_DAYS && getenv("PS_NO_ROW_BATCH") == nullptr) {
+    const bool batched_rows = row_inv_persistent(s) && !s->tinv && nd <= PS_MAX_GROUP_DAYS && getenv("PS_NO_ROW_BATCH") == nullptr;
+    // The two-role pass also sums |x|^2 over the pad-only rows of every day's intermediate; when even
+    // that total cannot lift one row pair to the flag threshold, the row pass leaves the pad-only
+    // pairs (21 % of the rows at N = 4097 on 5184) unread -- the per-pair Parseval test it would
+    // otherwise make after fetching them, decided for the whole day.  PS_NO_PAD_QUIET=1: A/B knob.
+    const bool quiet = batched_rows && colfull_dual(s, nd) && s->N + 1 < s->Pf && getenv("PS_NO_PAD_QUIET") == nullptr;
+    if (quiet) {
+      PS_TRY(s->pad_energy.ensure((size_t)nd * s->H));
+      PS_TRY(s->pad_quiet.ensure(PS_MAX_GROUP_DAYS));
+    }
+    // A chained pass is one workgroup per column for all nd days: 2593 columns on 256 CUs are ten
+    // full rounds and an eleventh for 33 columns (9 % of the launch).  Those last columns are taken out
+    // and spread over the chip day by day instead: their kernel columns' forward transforms (mode 1,
+    // every (column, day) its own workgroup), the chain of products element by element (k_prefix_cols),
+    // the inverse transforms (mode 2) -- three short launches, the same arithmetic in the same order.
+    // PS_NO_TAIL_SPLIT=1: A/B knob.
+    int hmain = s->H;
+    if (!s->ncu) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess) s->ncu = v;
+    }
+    if (colfull_dual(s, nd) && s->ncu > 0 && s->H > s->ncu && !s->tinv && getenv("PS_NO_TAIL_SPLIT") == nullptr) {
+      const int rem = s->H % s->ncu;
+      if (rem > 0 && rem * 3 <= s->ncu) hmain = s->H - rem;
+    }
+    PS_TRY(launch_colfull(s, 0, kt, state, 1, s->T1.p, 1, live, nullptr, nd, quiet ? s->pad_energy.p : nullptr, 0, hmain));
+    if (hmain < s->H) {
+      const int rem = s->H - hmain;
+      PS_TRY(s->tail_hat.ensure((size_t)nd * rem * s->Pf));
+      // pointers shifted so that column c lands at [c - hmain] of the scratch block
+      cplx* th = s->tail_hat.p - (int64_t)hmain * s->Pf;
+      {
+        ProfScope prof(s, PS_PROF_COL_TAIL, nd);
+        PS_TRY(launch_colfull(s, 1, kt, th, 0, nullptr, nd, live, nullptr, 1, nullptr, hmain, s->H, (int64_t)rem * s->Pf, false));
+        hipLaunchKernelGGL(k_prefix_cols, dim3((s->Pf + 255) / 256, rem), dim3(256), 0, s->stream,
+                           state + (int64_t)hmain * s->Pf, s->tail_hat.p, s->Pf, rem, nd);
+        PS_HIP(hipGetLastError());
+        PS_TRY(launch_colfull(s, 2, nullptr, th, 0, s->T1.p, nd, RowLive{0, {0, 0, 0, 0}, nullptr}, nullptr, 1,
+                              quiet ? s->pad_energy.p : nullptr, hmain, s->H, (int64_t)rem * s->Pf, false));
+      }
+    }
+    if (quiet) {
+      hipLaunchKernelGGL(k_pad_quiet, dim3(nd), dim3(256), 0, s->stream, s->pad_energy.p, s->H, (double)s->Pf,
+                         1.0 / ((double)s->Pf * (double)s->Pf), s->pad_floor, s->pad_quiet.p);
+      PS_HIP(hipGetLastError());
+    }
+    if (batched_rows) {
       // one launch for the rows of all nd days: nd x 2593 units over 256 persistent workgroups leave
       // 1/80 of a round idle at the end instead of 1/11 per day
-      PS_TRY(launch_row_inv(s, s->T1.p, nullptr, d0, nd, negval, stat_scale, false, recs));
+      PS_TRY(launch_row_inv(s, s->T1.p, nullptr, d0, nd, negval, stat_scale, false, recs, quiet ? s->pad_quiet.p : nullptr));
     } else {
       for (int i = 0; i < nd; ++i)
         PS_TRY(launch_row_inv(s, s->T1.p + i * spec, recs[i], d0 + i, 1, negval, stat_scale));

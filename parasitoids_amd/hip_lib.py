@@ -318,7 +318,7 @@ class HipSolve():
 
     PROF_CLASSES = ('row_fwd', 'col_fwd_a', 'col_fwd_b', 'col_inv_a', 'col_inv_b', 'row_inv',
                     'refft_pred', 'col_inv_a_x2', 'col_inv_a_x4', 'col_inv_a_x8',
-                    'row_inv_x2', 'row_inv_x4', 'row_inv_x8', 'col_inv_a_xn', 'row_inv_xn')
+                    'row_inv_x2', 'row_inv_x4', 'row_inv_x8', 'col_inv_a_xn', 'row_inv_xn', 'col_tail')
 
     def prof_enable(self, on=True, every=1):
         '''HIP-event timing per kernel class on the solver's stream; `every` = n times only

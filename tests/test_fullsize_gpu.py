@@ -403,3 +403,51 @@ def test_full_column_pipeline_matches_tiled_pipeline(hip_lib, monkeypatch):
         assert out['full_column'][1] == out['tiled'][1] and any(out['tiled'][1])
         for a, b in zip(out['full_column'][0] + out['full_column'][2], out['tiled'][0] + out['tiled'][2]):
             assert np.abs(a - b).max() <= 1e-14 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize('R,K,fft', [(1200, 1601, 3360), (1300, 1801, 3584)])
+def test_two_role_chained_pass_is_bit_identical(hip_lib, monkeypatch, R, K, fft):
+    """Long chained groups go through k_colfull_dual (two roles per workgroup: the inverse of day d
+    next to the forward transform of day d + 1, half-pass exchanges, inverse = conj-forward-conj,
+    kernel columns staged HBM -> LDS), and the batched row pass then leaves a day's pad-only row pairs
+    unread when the column pass found their total energy too small to matter.  Records, flags and
+    statistics must be BIT-identical to the single-role chained pass (PS_DUAL_MIN_DAYS=0) and to the
+    row pass that reads every pair (PS_NO_PAD_QUIET=1) -- on a clean chain (every day quiet), on one
+    whose mass reaches the pad without raising the flag, and on one that flags.  FFT size 3360 =
+    16 x 15 x 14, the smallest size the two-role pass serves; and 3584, whose 1793 columns are seven
+    rounds of 256 CUs plus ONE: that column leaves the chained pass and goes through the forward /
+    prefix-product / inverse launches (conv_inv_multi; PS_NO_TAIL_SPLIT=1 keeps it in)."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    nd = 14
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=11, sigma=(15.0, 40.0), shift=40)
+    for start, want_flag in ((R, False), (N - 251, None), (N - 71, True)):
+        state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
+        runs = {}
+        for tag, env in (('dual', {}), ('single', {'PS_DUAL_MIN_DAYS': '0'}), ('read_all', {'PS_NO_PAD_QUIET': '1'}),
+                         ('no_tail', {'PS_NO_TAIL_SPLIT': '1'})):
+            for k in ('PS_DUAL_MIN_DAYS', 'PS_NO_PAD_QUIET', 'PS_NO_TAIL_SPLIT'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            s = hip_lib.HipSolve(sparse.coo_matrix(([1.0], ([R], [R])), shape=(N, N)), [K, K], mode='fast', chain_only=True)
+            assert s.fft_len == fft and s.full_column
+            s.set_kernels(kernels)
+            s.run_chain(renorm=True)           # clean first run: the next one opens with one 14-day window
+            assert not any(x.flag for x in s.chain_stats(0, nd))
+            s.set_state(state)
+            s.prof_enable(True, every=1)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            if not any(x.flag for x in st):
+                assert s.prof_days()['col_inv_a_xn'] == nd       # one chained launch for the whole run
+            runs[tag] = ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta, x.padmax) for x in st])
+            s.close()
+        flags = [f for f, *_ in runs['single'][1]]
+        if want_flag is not None:
+            assert any(flags) == want_flag, flags
+        for tag in ('dual', 'read_all', 'no_tail'):
+            assert runs[tag][1] == runs['single'][1], tag
+            for a, b in zip(runs[tag][0], runs['single'][0]):
+                assert np.array_equal(a, b), tag
