@@ -92,7 +92,9 @@ def pmc_traffic(kernel_class):
         return None, None
     names, days = PMC_NAME[kernel_class]
     best = None
-    for e in json.load(open(files[-1])):
+    entries = json.load(open(files[-1]))
+    pmc_traffic.provenance = next((e for e in entries if e.get('kernel') == '__provenance__'), None)
+    for e in entries:
         if not e['kernel'].startswith(names) or e.get('write_size_MB') is None:
             continue
         if days is None and e.get('size_groups', 1) != 1:
@@ -107,6 +109,18 @@ def pmc_traffic(kernel_class):
     if best is None:
         return None, None
     return (best['fetch_corrected_MB'] + best['write_size_MB']) * 1024 * 1024, os.path.basename(files[-1])
+
+
+pmc_traffic.provenance = None
+
+
+def lib_sha256():
+    import hashlib
+    try:
+        from parasitoids_amd import _lib
+        return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+    except OSError:
+        return None
 
 
 def parse(argv=None):
@@ -245,6 +259,16 @@ def main():
         per = [float(x.item()) for x in allt]
         return max(per), per
 
+    def gather_parity(v):
+        """every rank's own device-vs-oracle figure on rank 0 (a rank on the wrong device, or with a
+        different result, cannot hide behind rank 0's)"""
+        if world == 1:
+            return [v]
+        t = torch.tensor([v], dtype=torch.float64, device='cuda' if on_gpu else 'cpu')
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        return [float(x.item()) for x in allt]
+
     R, K, nd = args.rad_res, args.kshape, args.ndays
     N = 2 * R + 1
     P = N + K // 2
@@ -252,11 +276,17 @@ def main():
     if args.rehearse:
         dist.barrier() if world > 1 else None
         dt, per = gather_times(1.0 + 0.0 * rank)
+        mg = None
+        if world > 1:
+            import bench_extras
+            mg = bench_extras.multi_gpu_record(rank, world, rehearse=True)      # configs 4 / 5 control flow, stand-in work
+            par = gather_parity(1e-19 * (rank + 1))
         if rank == 0:
             print(json.dumps({'metric': 'grid-days/sec on 4096^2 fp64 domain', 'value': None,
                               'unit': 'grid-days/s', 'n_gpus': dist.get_world_size() if world > 1 else 1,
                               'steps': args.steps, 'warmup': args.warmup, 'rehearsal': True,
-                              'ranks_seen': len(per), 'backend': backend}))
+                              'ranks_seen': len(per), 'backend': backend,
+                              'multi_gpu': mg, 'parity': {'per_rank_max_abs': par} if world > 1 else None}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -316,6 +346,12 @@ def main():
     prof_days = solver.prof_days()
     solver.prof_enable(False)
     dt, per_rank = gather_times(dt_own)
+    rank_parity = None
+    if world > 1 and not args.no_cpu_baseline:
+        # every rank checks ITS stack against the oracle (2 day steps, ~5 s of one host core each)
+        _, of = cpu_baseline(state, kernels, K, 2)
+        rank_parity = gather_parity(max_abs_vs(solver, of))
+        del of
 
     if rank == 0:
         nranks = dist.get_world_size() if world > 1 else 1
@@ -356,7 +392,10 @@ def main():
                               'note': 'HIP-event profiling disabled'}))
             return
         # total time per class: multi-day launches are all timed, the others every PROF_EVERY-th
-        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches']
+        # (only classes with a byte model: the HIP-event durations of `row_fwd` include the wait of the
+        # low-priority kernel-transform launches for idle CUs behind the day passes, not work)
+        cand = [k for k in kern if kern[k].get('hbm_GBps')] or list(kern)
+        dom = max(cand, key=lambda k: kern[k]['avg_ms'] * kern[k]['timed_launches']
                   * (1 if k in days_of else PROF_EVERY))
         ach = kern[dom].get('hbm_GBps')
         traffic, traffic_src = pmc_traffic(dom) if (R, K, nd) == (2048, 2049, 30) else (None, None)
@@ -398,7 +437,14 @@ def main():
                          'days_per_launch': days_of.get(dom, 1),
                          'avg_launch_ms': kern[dom]['avg_ms'],
                          'traffic_source': ('profiles/%s (committed rocprofv3 --pmc summary, not '
-                                            'collected in this run)' % traffic_src) if traffic_src else None},
+                                            'collected in this run)' % traffic_src) if traffic_src else None,
+                         # which build the committed counters were collected from, and whether it is the
+                         # library timed here (a stale summary shows as false)
+                         'traffic_provenance': ({'git_head': pmc_traffic.provenance.get('git_head'),
+                                                 'lib_sha256': pmc_traffic.provenance.get('lib_sha256'),
+                                                 'this_lib_sha256': lib_sha256(),
+                                                 'same_library': pmc_traffic.provenance.get('lib_sha256') == lib_sha256()}
+                                                if (traffic_src and pmc_traffic.provenance) else None)},
             'kernels': kern,
         }
         if dom.startswith('col_inv_a') and solver.full_column:
@@ -436,6 +482,9 @@ def main():
             par['ok'] = all(v < 1e-12 for k, v in par.items() if k.startswith('max_abs'))
             out['parity'] = par
             del ofields
+        if rank_parity is not None:
+            out['parity'] = {'days': 2, 'tolerance': 1e-12, 'per_rank_max_abs': rank_parity,
+                             'ok': all(v < 1e-12 for v in rank_parity)}
         if nranks == 1 and not args.no_extras and (R, K, nd) == (2048, 2049, 30):
             solver.close()
             import bench_extras
@@ -445,6 +494,18 @@ def main():
                     out[key] = fn(device=local)
                 except Exception as e:          # a sub-record must not cost the headline line
                     out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+    mg = None
+    if world > 1 and not args.no_extras and (R, K, nd) == (2048, 2049, 30):
+        # configs 4 and 5 over the ranks of this job (every rank takes part in the gathers)
+        solver.close()
+        import bench_extras
+        try:
+            mg = bench_extras.multi_gpu_record(rank, world, device=local)
+        except Exception as e:
+            mg = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0:
+        if mg is not None:
+            out['multi_gpu'] = mg
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -120,7 +120,7 @@ def _oracle_day(args):
     return time.perf_counter() - t0, p.shape[0], p.nnz
 
 
-def bayes_cpu_baseline(rad_res, days, all_cores=True):
+def bayes_cpu_baseline(rad_res, days, all_cores=True, eval_fraction=None):
     """The oracle's model evaluation (18 x prob_mass + 17 chain days) on the host: prob_mass of
     ONE day and 2 chain days on one core, extrapolated (`cores: 1`); and, like the reference
     runs it, the 18 prob_mass calls spread over a process pool (`all_cores`)."""
@@ -144,10 +144,15 @@ def bayes_cpu_baseline(rad_res, days, all_cores=True):
             hat = OC.fft2(A, ms)
     t_day = (time.perf_counter() - t0) / 2
     nd = len(days)
-    rec = {'value': round(3600.0 / (nd * t_pm + (nd - 1) * t_day), 2), 'unit': 'samples/hour', 'cores': 1,
+    ev1 = 3600.0 / (nd * t_pm + (nd - 1) * t_day)
+    frac = eval_fraction if eval_fraction else 1.0
+    rec = {'value': round(ev1, 2), 'unit': 'evaluations/hour', 'cores': 1,
            'kind': 'port',
+           'samples_per_hour_at_the_gpu_chain_evaluation_fraction': round(ev1 / frac, 2),
+           'evaluation_fraction': eval_fraction,
            'sample': 'oracle prob_mass of 1 day (%.1fs) and 2 chain days (%.2fs each) at R=%d, extrapolated to '
-                     '%d + %d; one model evaluation per MCMC sample' % (t_pm, t_day, rad_res, nd, nd - 1)}
+                     '%d + %d = one model evaluation; samples/hour = evaluations/hour / the fraction of the GPU '
+                     'chain\'s samples that evaluated the model' % (t_pm, t_day, rad_res, nd, nd - 1)}
     if all_cores:
         import multiprocessing as mp
         ncpu = os.cpu_count() or 1
@@ -157,7 +162,9 @@ def bayes_cpu_baseline(rad_res, days, all_cores=True):
         with ctx.Pool(nproc) as pool:
             res = pool.map(_oracle_day, [(d, rad_res) for d in days])
         t_pool = time.perf_counter() - t0
-        rec['all_cores'] = {'value': round(3600.0 / (t_pool + (nd - 1) * t_day), 2), 'unit': 'samples/hour',
+        evp = 3600.0 / (t_pool + (nd - 1) * t_day)
+        rec['all_cores'] = {'value': round(evp, 2), 'unit': 'evaluations/hour',
+                            'samples_per_hour_at_the_gpu_chain_evaluation_fraction': round(evp / frac, 2),
                             'cores': nproc, 'host_cpus': ncpu,
                             'sample': 'the %d prob_mass days of one evaluation over a %d-process pool (%.1fs wall '
                                       'incl. start-up, slowest day %.1fs) + %d chain days on one core (%.2fs each)'
@@ -178,24 +185,35 @@ def bayes_case(rad_res, mode, samples, burn, device=None, seed=1000):
         chain = mcmc.Sampler(pm, li, (10000.0 / rad_res) ** 2, seed=seed)
         chain.run(burn)
         res = chain.run(samples)
+    ev = res['evaluations_this_run']
     rec = {'value': round(res['samples_per_hour'], 1), 'unit': 'samples/hour', 'rad_res': rad_res,
            'grid': '%d^2' % (2 * rad_res + 1), 'mode': pm.solver.mode, 'fft_len': pm.solver.fft_len,
            'samples': samples, 'burn': burn, 'ms_per_sample': round(1e3 * res['seconds'] / samples, 3),
-           'acceptance': round(res['acceptance'], 3), 'evaluations': res['evaluations_this_run'],
+           'timed_window_s': round(res['seconds'], 3),
+           'acceptance': round(res['acceptance'], 3), 'evaluations': ev,
+           # a sample whose block proposal leaves the priors' support costs no model evaluation
+           # (mcmc.Sampler.step; PyMC2 skips the deterministic for a -inf prior as well)
+           'evaluations_per_hour': round(3600.0 * ev / res['seconds'], 1),
+           'evaluation_fraction': round(ev / float(samples), 4),
            'failed_evaluations': res['failed_evaluations'],
            'logp_first_last': [round(float(res['logp'][0]), 3), round(float(res['logp'][-1]), 3)]}
     pm.close()
     return rec, days
 
 
-def bayes_record(device=None, samples=150, burn=20, cpu=True):
+def bayes_record(device=None, samples=600, burn=50, cpu=True):
     """BASELINE.json's second metric: Bayes_Run MCMC samples/hour on the Kalbar data -- one
     chain on one GPU with the in-repo sampler (parasitoids_amd/mcmc.py: AdaptiveMetropolis block
     + scalar Metropolis steps, the reference's priors and Poisson observation model, Kalbar wind
-    and the Kalbar field observations through Data_Import.LocInfo).  One sample = one
-    pop_model evaluation (18 x prob_mass + get_populations + observation gathers) + the scalar
-    updates.  R = 400 is the reference's hard-coded grid (Bayes_Run.py:91), R = 512 the
-    1024^2 grid BASELINE config 4 names."""
+    and the Kalbar field observations through Data_Import.LocInfo).  One sample = one block
+    proposal -- a pop_model evaluation (18 x prob_mass + get_populations + observation gathers)
+    UNLESS the proposal leaves the priors' support, which costs none -- + the scalar updates;
+    `evaluations_per_hour` / `evaluation_fraction` say how many of the timed samples evaluated the
+    model, and the CPU baselines are stated in evaluations/hour with the samples/hour they would
+    give at that same fraction.  R = 400 is the reference's hard-coded grid (Bayes_Run.py:91),
+    R = 512 the 1024^2 grid BASELINE config 4 names.  The timed window is `samples` samples after
+    `burn` (AdaptiveMetropolis: delay = 1000, so the window samples with the initial proposal
+    scales, like the first 1000 iterations of the reference's run)."""
     out = {'metric': 'Bayes_Run MCMC samples/hour (Kalbar)', 'unit': 'samples/hour', 'chains': 1,
            'sampler': 'AdaptiveMetropolis(15 model parameters; scales, interval=500, delay=1000, '
                       'shrink_if_necessary) + scalar Metropolis on xi, em_obs_prob, grid_obs_prob, '
@@ -210,13 +228,172 @@ def bayes_record(device=None, samples=150, burn=20, cpu=True):
                 out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
     if 'value' in out.get('r400_auto', {}):
         out['value'] = out['r400_auto']['value']            # exact-torus results at the reference's grid
+    if 'evaluations_per_hour' in out.get('r400_auto', {}):
+        out['evaluations_per_hour'] = out['r400_auto']['evaluations_per_hour']
     if cpu and days is not None:
         for R in (400, 512):
             try:
-                out['cpu_baseline_r%d' % R] = bayes_cpu_baseline(R, days, all_cores=True)
+                frac = out.get('r%d_auto' % R, {}).get('evaluation_fraction')
+                out['cpu_baseline_r%d' % R] = bayes_cpu_baseline(R, days, all_cores=True, eval_fraction=frac)
             except Exception as e:
                 out['cpu_baseline_r%d' % R] = {'error': '%s: %s' % (type(e).__name__, e)}
+    try:
+        out['prob_mass_roofline'] = prob_mass_roofline(device=device)
+    except Exception as e:
+        out['prob_mass_roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     return out
+
+
+# estimated fp64 operations per rectangle probability of the device pipeline (model_kernels.h):
+# one bivariate-normal corner value -- Genz BVU, |rho| < 0.3: 3 Gauss-Legendre points = 6 exponentials
+# of ~30 operations each (argument, exp, weighted accumulate) + 7 around them -- per cell (the
+# (2H+2)^2 corner grid of a (2H+1)^2 stamp), + 5 for the cell mass (three differences, x hprob, the
+# ordered add).  The Phi (erfc) values are per row / column edge of the corner grid, not per corner.
+EXP_PER_CORNER = 6
+FLOPS_PER_RECT = 6 * 30 + 7 + 5
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md
+
+
+def prob_mass_roofline(device=None, rad_res=400, reps=10):
+    """SURVEY 8d's roofline for the prob_mass half of a Bayes evaluation (compute-bound: fp64 VALU +
+    transcendentals, not HBM): the 18 Kalbar days at the reference's grid, default parameters --
+    rectangle probabilities per second (one per cell of every period's stamp, what the reference
+    spends 97 % of prob_mass on: ParasitoidModel.py:311-380), estimated fp64 rate against the
+    vector peak, and the HBM bytes of the same batch from the committed rocprofv3 PMC summary."""
+    import glob
+    import json
+    import re
+    from parasitoids_amd import ParasitoidModel as PM
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    model = PM.WindModel(wd, device)
+    args = (days, HP, DP, DLP, MU_R, NPER, 10000.0, rad_res)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        model.build(*args)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model.build(*args)                       # returns after the batch's statistics are on the host
+        dt = (time.perf_counter() - t0) / reps
+    rect = corners = periods = 0
+    for i in range(len(days)):
+        dbg = model.debug(i)
+        live = dbg['hprob'] > 0
+        H = dbg['H'][live].astype(np.int64)
+        rect += int(((2 * H + 1) ** 2).sum())
+        corners += int(((2 * H + 2) ** 2).sum())
+        periods += int(live.sum())
+    model.close()
+    tf = rect * FLOPS_PER_RECT / dt / 1e12
+    rec = {'workload': 'prob_mass of the %d Kalbar days, R = %d, default parameters (one Bayes evaluation\'s kernels)'
+                       % (len(days), rad_res),
+           'ms_per_batch': round(dt * 1e3, 3), 'periods': periods, 'rect_probs': rect, 'corner_values': corners,
+           'rect_probs_per_s': round(rect / dt, 1), 'bound': 'fp64 VALU + transcendentals',
+           'exp_per_corner': EXP_PER_CORNER, 'est_flops_per_rect_prob': FLOPS_PER_RECT,
+           'achieved': round(tf, 2), 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s (estimated)',
+           'frac': round(tf / FP64_VALU_PEAK_TFLOPS, 4),
+           'note': 'wall time of the whole batch (periods, pair lists, corner values, ordered accumulate, '
+                   'threshold, compaction, statistics to the host); the corner values (k_pair_masses) are '
+                   'about half of it, see profiles/'}
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*prob_mass_hbm_traffic.json')),
+                   key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
+    if files:
+        try:
+            pm = json.load(open(files[-1]))
+            rec['hbm'] = {'source': 'profiles/%s (committed rocprofv3 --pmc summary of the same batch)' % os.path.basename(files[-1])}
+            rec['hbm'].update(pm.get('summary', {}))
+            tot = pm.get('summary', {}).get('total_bytes_per_batch')
+            if tot:
+                rec['hbm']['GBps_at_measured_time'] = round(tot / dt / 1e9, 1)
+                rec['hbm']['frac_of_8000'] = round(tot / dt / 1e9 / 8000.0, 4)
+        except Exception as e:       # a malformed summary must not cost the record
+            rec['hbm'] = {'error': str(e)}
+    return rec
+
+
+# --------------------------------------------------------------------------- N > 1: configs 4 and 5
+def _ensemble_runner(device, rad_res, ndays):
+    """member -> result dict on this rank's GPU (BASELINE config 5: probability model, Carnarvon wind)"""
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd.pop_model import PopModel
+    wd, days = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    model = PopModel(wd, days, domain_info=(10000.0, rad_res), r_start=0.354, mode='fast', prob_model=True,
+                     device=device)
+    g, f = (1.263, 3.913), (7.302, 2.614, 23.999, 2.350)
+
+    def run(mem):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            st = model.evaluate((mem['lam'],) + g + f, (mem['sig_x'], mem['sig_y'], 0.253), (7.096, 7.260, 0.0),
+                                mem['mu_r'], 30, ndays=ndays)
+        tot = model.moments(ndays - 1)[0]
+        return {'total': float(tot), 'nnz_last': int(st[-1][0])}
+    return run, model
+
+
+def multi_gpu_record(rank, world, device=None, rehearse=False, members_per_rank=4, rad_res=1024, ndays=30,
+                     chain_samples=300, chain_burn=30):
+    """What the N-rank job is for besides replica stacks: BASELINE config 5 -- ensemble
+    members round-robin over the ranks (`parallel.run_members`, results gathered on rank 0) -- and
+    config 4 -- one independent MCMC chain per rank, chain c seeded 1000 + c.  No data-path
+    collective; the gathers carry small python objects.  Returns the record on rank 0, None elsewhere.
+    `rehearse`: the same control flow with stand-in evaluation functions (CPU test, gloo)."""
+    from parasitoids_amd import parallel
+    from parasitoids_amd.synthetic import ensemble_members
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    out = {'n_gpus': world}
+    # ---- config 5
+    members = ensemble_members(members_per_rank * world)
+    if rehearse:
+        model = None
+        run = lambda mem: {'total': 1.0, 'nnz_last': int(1000 * mem['lam'])}
+    else:
+        run, model = _ensemble_runner(device, rad_res, ndays)
+        run(members[rank])                      # warm-up: solvers, plans, buffers
+    barrier()
+    t0 = time.perf_counter()
+    res = parallel.run_members(members, run)
+    dt_own = time.perf_counter() - t0           # this rank's members (rank 0: + the gather)
+    own = len(members[rank::world])
+    times = parallel.gather_objects((rank, own, dt_own))
+    if model is not None:
+        model.close()
+    if rank == 0:
+        dt = max(t for _, _, t in times)
+        out['ensemble'] = {'workload': 'BASELINE config 5: %d members (lambda, sigma, mu_r from the priors) x %d^2 grid x '
+                                       '%d Carnarvon days, probability model, member i on rank i mod %d'
+                                       % (len(members), 2 * rad_res + 1, ndays, world),
+                           'value': round(len(members) / dt, 3), 'unit': 'members/s',
+                           'member_grid_days_per_s': round(len(members) * (ndays - 1) / dt, 1),
+                           'seconds': round(dt, 3),
+                           'per_rank_members_per_s': [round(n / t, 3) for _, n, t in sorted(times)],
+                           'members_gathered': len(res),
+                           'all_members_conserve_mass': bool(all(abs(r['total'] - 1.0) < 1e-6 or r['total'] < 1.0 + 1e-9 for r in res))}
+    # ---- config 4
+    seed = 1000 + rank
+    if rehearse:
+        rec = {'value': 1.0e6 + seed, 'evaluations_per_hour': 0.8e6, 'evaluation_fraction': 0.8, 'acceptance': 0.4,
+               'timed_window_s': 1.0, 'samples': chain_samples}
+    else:
+        rec, _ = bayes_case(400, 'auto', chain_samples, chain_burn, device, seed=seed)
+    barrier()
+    chains = parallel.gather_objects((rank, seed, rec))
+    if rank == 0:
+        chains = sorted(chains)
+        out['bayes'] = {'workload': 'BASELINE config 4: %d independent chains, one per rank, chain c seeded 1000 + c, '
+                                    'Kalbar, R = 400 (the reference\'s grid), exact-torus results' % world,
+                        'value': round(sum(r['value'] for _, _, r in chains), 1), 'unit': 'samples/hour (sum over chains)',
+                        'evaluations_per_hour': round(sum(r['evaluations_per_hour'] for _, _, r in chains), 1),
+                        'seeds': [sd for _, sd, _ in chains],
+                        'per_rank_samples_per_hour': [r['value'] for _, _, r in chains],
+                        'per_rank_acceptance': [r['acceptance'] for _, _, r in chains],
+                        'samples_per_chain': chain_samples}
+        return out
+    return None
 
 
 if __name__ == '__main__':
@@ -225,5 +402,7 @@ if __name__ == '__main__':
     if which == 'real_wind':
         R = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
         print(json.dumps(real_wind_record(R=R)))
+    elif which == 'prob_mass':
+        print(json.dumps(prob_mass_roofline()))
     else:
         print(json.dumps(bayes_record()))

@@ -46,3 +46,17 @@ def moments(M):
     vr = (M.data * (M.row - mr) ** 2).sum() / s
     vc = (M.data * (M.col - mc) ** 2).sum() / s
     return s, mr, mc, vr, vc
+
+
+def ensemble_members(m, seed=512):
+    """BASELINE config 5: `m` samples of (lambda, sigma_x, sigma_y, mu_r) from the reference's
+    priors -- lambda ~ Beta(5, 1), sigma_x ~ Gamma(26, rate 0.15), sigma_y ~ Gamma(15, rate 0.15),
+    mu_r ~ N(1, 1) truncated > 0 (Bayes_Run.py:102, :116-117, :129), `default_rng(512)`."""
+    rng = np.random.default_rng(seed)
+    lam = rng.beta(5, 1, m)
+    sx = rng.gamma(26, 1 / 0.15, m)
+    sy = rng.gamma(15, 1 / 0.15, m)
+    mu = rng.normal(1, 1, 4 * m)
+    mu = mu[mu > 0][:m]
+    return [dict(lam=float(lam[i]), sig_x=float(sx[i]), sig_y=float(sy[i]), mu_r=float(mu[i]))
+            for i in range(m)]

@@ -11,6 +11,11 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
+# provenance: which source tree and which library build these numbers belong to (the GPU box has no
+# .git: scripts/gpu_profiles.sh leaves the commit in .git_head before it ships the tree)
+{ echo "git_head $(cat "$root/.git_head" 2>/dev/null || git -C "$root" rev-parse HEAD 2>/dev/null || echo unknown)";
+  echo "lib_sha256 $(sha256sum "$root/parasitoids_amd/libparasitoid_hip.so" | cut -d' ' -f1)";
+  echo "date $(date -u +%Y-%m-%dT%H:%M:%SZ)"; } > "$out/provenance.txt"
 run() {  # name, rocprof args..., -- program args
   local name=$1; shift
   rocprofv3 "$@" > "$out/$name.log" 2>&1 || { echo "rocprofv3 failed for $name"; tail -5 "$out/$name.log"; }
@@ -20,10 +25,10 @@ run bench_stats --kernel-trace --stats -d "$out/bench_stats" -o b --output-forma
   python3 "$root/bench.py" --steps 5 --warmup 2 --no-extras --no-cpu-baseline
 # 2. HBM traffic of the same command
 BENCH_NO_PROF=1 run bench_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/bench_fetch" -o p --output-format csv -- \
-  python3 "$root/bench.py" --steps 1 --warmup 1 --no-extras --no-cpu-baseline
+  python3 "$root/bench.py" --steps 2 --warmup 2 --no-extras --no-cpu-baseline
 BENCH_NO_PROF=1 run bench_write --kernel-trace --pmc WRITE_SIZE -d "$out/bench_write" -o p --output-format csv -- \
-  python3 "$root/bench.py" --steps 1 --warmup 1 --no-extras --no-cpu-baseline
-python3 "$root/scripts/hbm_traffic.py" "$out/bench_fetch" "$out/bench_write" "$out/bench_hbm_traffic_pmc.json" > "$out/bench_hbm_traffic.txt"
+  python3 "$root/bench.py" --steps 2 --warmup 2 --no-extras --no-cpu-baseline
+python3 "$root/scripts/hbm_traffic.py" "$out/bench_fetch" "$out/bench_write" "$out/bench_hbm_traffic_pmc.json" "$out/provenance.txt" > "$out/bench_hbm_traffic.txt"
 # 3. the real-wind chains (Carnarvon, R = 2048: full-column pipeline, flags, fold path)
 run rw_stats --kernel-trace --stats -d "$out/rw_stats" -o b --output-format csv -- \
   python3 "$root/bench_extras.py" real_wind
@@ -31,7 +36,16 @@ run rw_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/rw_fetch" -o p --output-fo
   python3 "$root/bench_extras.py" real_wind
 run rw_write --kernel-trace --pmc WRITE_SIZE -d "$out/rw_write" -o p --output-format csv -- \
   python3 "$root/bench_extras.py" real_wind
-python3 "$root/scripts/hbm_traffic.py" "$out/rw_fetch" "$out/rw_write" "$out/rw_hbm_traffic_pmc.json" > "$out/rw_hbm_traffic.txt"
+python3 "$root/scripts/hbm_traffic.py" "$out/rw_fetch" "$out/rw_write" "$out/rw_hbm_traffic_pmc.json" "$out/provenance.txt" > "$out/rw_hbm_traffic.txt"
+# 4. the prob_mass half of a Bayes evaluation: kernel statistics and HBM bytes of the 18-day batch
+#    (bench_extras.py prob_mass builds it 1 + 10 times)
+run pm_stats --kernel-trace --stats -d "$out/pm_stats" -o b --output-format csv -- \
+  python3 "$root/bench_extras.py" prob_mass
+run pm_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/pm_fetch" -o p --output-format csv -- \
+  python3 "$root/bench_extras.py" prob_mass
+run pm_write --kernel-trace --pmc WRITE_SIZE -d "$out/pm_write" -o p --output-format csv -- \
+  python3 "$root/bench_extras.py" prob_mass
+(cd "$root/scripts" && python3 prob_mass_traffic.py "$out/pm_fetch" "$out/pm_write" 11 "$out/prob_mass_hbm_traffic.json") > "$out/prob_mass_hbm_traffic.txt"
 find "$out" -name "*kernel_stats.csv" | head
 # keep the merge small: raw traces stay on the box
 find "$out" -name "*kernel_trace.csv" -delete

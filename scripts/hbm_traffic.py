@@ -7,7 +7,7 @@ nor the dynamic LDS size), so a group whose WRITE_SIZE values fall into separate
 than 25 % apart) is split into them; `size_rank` / `size_groups` say which cluster an entry is
 (ascending bytes: 2, 4, 8 days per launch).  Both passes run the same deterministic command, so the
 k-th dispatch of a kernel in the FETCH pass is the k-th in the WRITE pass.
-usage: hbm_traffic.py FETCH_DIR WRITE_DIR OUT.json"""
+usage: hbm_traffic.py FETCH_DIR WRITE_DIR OUT.json [PROVENANCE.txt]"""
 import csv
 import glob
 import json
@@ -40,7 +40,20 @@ def clusters(vals):
     return out
 
 
-def main(fd, wd, out):
+def provenance(path):
+    """{'git_head': ..., 'lib_sha256': ..., 'date': ...} from collect_profiles.sh's provenance.txt"""
+    rec = {'kernel': '__provenance__'}
+    try:
+        for line in open(path):
+            k, _, v = line.strip().partition(' ')
+            if k:
+                rec[k] = v
+    except OSError:
+        pass
+    return rec
+
+
+def main(fd, wd, out, prov=None):
     f = read(fd, 'FETCH_SIZE')
     w = read(wd, 'WRITE_SIZE')
     res = []
@@ -57,10 +70,12 @@ def main(fd, wd, out):
                  'write_size_MB': (sum(wv[i] for i in idx) / n / 1024.0) if wv is not None and len(wv) == len(fv)
                  else ((sum(wv) / len(wv) / 1024.0) if wv else None)}
             res.append(e)
+    if prov:
+        res.append(provenance(prov))     # which build these counters belong to (bench.py echoes it)
     json.dump(res, open(out, 'w'), indent=1)
     for e in res[:10]:
         print(e)
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

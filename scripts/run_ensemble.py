@@ -21,14 +21,8 @@ sys.path.insert(0, ROOT)
 
 
 def draw_members(m, seed=512):
-    rng = np.random.default_rng(seed)
-    lam = rng.beta(5, 1, m)
-    sx = rng.gamma(26, 1 / 0.15, m)
-    sy = rng.gamma(15, 1 / 0.15, m)
-    mu = rng.normal(1, 1, 4 * m)
-    mu = mu[mu > 0][:m]
-    return [dict(lam=float(lam[i]), sig_x=float(sx[i]), sig_y=float(sy[i]), mu_r=float(mu[i]))
-            for i in range(m)]
+    from parasitoids_amd.synthetic import ensemble_members
+    return ensemble_members(m, seed)
 
 
 def main():

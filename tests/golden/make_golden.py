@@ -4,7 +4,7 @@
 Run in the build container only (it imports /root/reference, which does not
 exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]     # groups: g1 .. g8
+    python tests/golden/make_golden.py [group ...]     # groups: g1 .. g9, g5b
 
 Three harness-side shims, none of which touch the
 reference: (1) scipy 1.15 no longer exposes `scipy.stats.mvn`; the same Genz
@@ -199,6 +199,62 @@ def g5():
     save('g5_prob_mass', **out)
 
 
+def coo_digest(prefix, M, out, every):
+    """A big COO kernel as shape, nnz, sum, a SHA-256 over its (row, col) pattern in the
+    reference's entry order and every `every`-th entry (index, row, col, value) -- a full dump
+    of a 1600^2 kernel would be several MB."""
+    import hashlib
+    M = M.tocoo()
+    row, col = M.row.astype(np.int32), M.col.astype(np.int32)
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(row).tobytes())
+    h.update(np.ascontiguousarray(col).tobytes())
+    out[prefix + '_shape'] = np.array(M.shape, dtype=np.int64)
+    out[prefix + '_nnz'] = np.int64(M.nnz)
+    out[prefix + '_sum'] = np.float64(M.data.sum())
+    out[prefix + '_pattern_sha256'] = np.frombuffer(h.digest(), dtype=np.uint8).copy()
+    idx = np.arange(0, M.nnz, every, dtype=np.int64)
+    out[prefix + '_samp_idx'] = idx
+    out[prefix + '_samp_row'] = row[idx]
+    out[prefix + '_samp_col'] = col[idx]
+    out[prefix + '_samp_val'] = M.data[idx].astype(np.float64)
+    # the entry with the largest value and the bounding rows / columns pin the shrink (ParasitoidModel.py:606-613)
+    out[prefix + '_argmax'] = np.int64(np.argmax(M.data))
+
+
+def g5b():
+    """prob_mass at the grid sizes of BASELINE configs 2-5 (the tile / pair / ordered
+    accumulate pipeline above R = 400 was only pinned through sum = 1 properties): Kalbar at
+    R = 512 (config 4's grid), a prior-drawn ensemble member of config 5 on Carnarvon at R = 1024,
+    and Carnarvon at R = 2048 (config 3) for a late release (about 100 periods)."""
+    out = {}
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    wc, dc = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    # member 0 of scripts/run_ensemble.py:draw_members(512) -- lambda ~ Beta(5,1), sigma_x ~ Gamma(26, rate .15),
+    # sigma_y ~ Gamma(15, rate .15), mu_r ~ N(1,1) > 0 (Bayes_Run.py:102,:116-117,:129)
+    rng = np.random.default_rng(512)
+    lam = rng.beta(5, 1, 512)
+    sx = rng.gamma(26, 1 / 0.15, 512)
+    sy = rng.gamma(15, 1 / 0.15, 512)
+    mu = rng.normal(1, 1, 4 * 512)
+    mu = mu[mu > 0][:512]
+    hp5 = (float(lam[0]),) + HP[1:]
+    dp5 = (float(sx[0]), float(sy[0]), 0.253)
+    out['member0'] = np.array([lam[0], sx[0], sy[0], mu[0]])
+    args = [(days[0], wd, HP, DP, DLP, MU_R, NPER, 10000.0, 512),
+            (dc[3], wc, hp5, dp5, DLP, float(mu[0]), NPER, 10000.0, 1024),
+            (dc[0], wc, HP, DP, DLP, MU_R, NPER, 10000.0, 2048, 0.93)]
+    out['kal512_day'] = np.int64(days[0])
+    out['car1024_day'] = np.int64(dc[3])
+    out['car2048_day'] = np.int64(dc[0])
+    with Pool(3) as pool:
+        res = pool.map(_pm, args)
+    for nm, r, every in zip(('kal512', 'car1024_member0', 'car2048_late'), res, (7, 23, 23)):
+        coo_digest(nm, r, out, every)
+        print(nm, r.shape, r.nnz, r.data.sum())
+    save('g5b_prob_mass_large', **out)
+
+
 def _kalbar_pmfs(R, nd):
     wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
     args = [(d, wd, HP, DP, DLP, MU_R, NPER, 10000.0, R) for d in days[:nd]]
@@ -389,7 +445,7 @@ def g9():
     save('g9_bayes_funcs', **out)
 
 
-GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}
+GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g5b': g5b, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(GROUPS)

@@ -24,6 +24,17 @@ def test_bench_gpus2_launches_two_ranks():
     assert len(lines) == 1                      # rank 0 only
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['rehearsal'] is True
+    # BASELINE configs 4 and 5 over the ranks (stand-in work here): members round-robin and
+    # gathered in member order, one chain per rank with seeds 1000 + rank, per-rank parity figures
+    mg = d['multi_gpu']
+    assert mg['n_gpus'] == 2
+    ens = mg['ensemble']
+    assert ens['members_gathered'] == 8 and len(ens['per_rank_members_per_s']) == 2 and ens['value'] > 0
+    by = mg['bayes']
+    assert by['seeds'] == [1000, 1001] and len(by['per_rank_samples_per_hour']) == 2
+    assert abs(by['value'] - sum(by['per_rank_samples_per_hour'])) < 1.0
+    assert by['per_rank_samples_per_hour'][1] - by['per_rank_samples_per_hour'][0] == 1.0   # each rank ran its own seed
+    assert d['parity']['per_rank_max_abs'] == [1e-19, 2e-19]
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
