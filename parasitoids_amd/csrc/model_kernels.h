@@ -125,6 +125,19 @@ __device__ __forceinline__ double pm_bvu_phi(const BvuRule& R, double h, double 
   return bvn * R.asr / (2 * TWOPI) + ph * pk;
 }
 
+// the |rho| < 0.925 branch of pm_bvu_phi on its own (identical arithmetic)
+__device__ __forceinline__ double pm_bvu_low_phi(const BvuRule& R, double h, double k, double ph, double pk) {
+  const double TWOPI = 6.283185307179586;
+  const double hk = h * k;
+  const double hs = (h * h + k * k) / 2;
+  double bvn = 0.0;
+  for (int i = 0; i < R.lg; ++i) {
+    bvn = bvn + R.w[i] * exp((R.sn1[i] * hk - hs) * R.iv1[i]);
+    bvn = bvn + R.w[i] * exp((R.sn2[i] * hk - hs) * R.iv2[i]);
+  }
+  return bvn * R.asr / (2 * TWOPI) + ph * pk;
+}
+
 // rectangle probability of N(mu, S) on [xl,xu] x [yl,yu] as mvnun computes it
 __device__ __forceinline__ double pm_rect(const BvuRule& R, double sdx, double sdy, double mux,
                                           double muy, double xl, double xu, double yl, double yu) {
@@ -480,31 +493,66 @@ k_tile_fill(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo*
   }
 }
 
-// one wave per pair (4 pairs per 256-thread workgroup, same phase structure -> plain barriers)
-__global__ void __launch_bounds__(256)
-k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int nt, long long npairs,
+// LDS traffic of ONE wave: its own writes are visible to its own later reads once the LDS queue
+// has drained (in-order per wave); the "memory" clobber keeps the compiler from moving accesses
+#define PM_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// One wave per SEGMENT of `seg` consecutive entries of the ordered pair list (4 segments per
+// 256-thread workgroup; the waves share nothing, so there is no workgroup barrier and a wave whose
+// pairs have few corners under their window does not wait for its neighbours).  For every pair:
+// the Phi factors of the needed column / row edges, the BVU corner values of the part of the tile
+// under the stamp window, the 256 cell masses times hprob[t] -- added, in list order, to a record
+// held in registers.  The record goes to hm[first pair of the run] whenever the tile changes inside
+// the segment and at its end: runs start at the first pair of a tile and at every multiple of
+// `seg`, which is where k_tile_accumulate looks for them.  With seg = 1 every pair has its own
+// record and the sums are those of a sequential loop over the periods bit for bit (the reference's
+// order, ParasitoidModel.py:539-540); seg = 8 (default) adds eight periods at a time before the
+// ordered pass -- 1/8 of the 2 KB records (850 MB written and read back per 18-day evaluation at
+// R = 400 otherwise), sums regrouped at the 1e-16 level, still the same on every run.
+// HIGH: the correlation takes Genz's |rho| >= 0.925 branch (uniform per batch; the host picks the
+// instance).  Keeping that branch out of the common instance is worth 50 registers: 165 -> ~110,
+// i.e. four resident waves per SIMD instead of three.
+template <bool HIGH>
+__global__ void __launch_bounds__(256, HIGH ? 2 : 4)   // common instance: 128 registers (2 spilled), four waves per SIMD
+k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int nt, long long npairs, int seg,
               const int* __restrict__ pair_t, const int* __restrict__ pair_tile, double* __restrict__ hm) {
   __shared__ double s_b[4][PM_NC];
   __shared__ double s_px[4][PM_TS + 1], s_py[4][PM_TS + 1];   // Phi(-h_a), Phi(-k_b)
   __shared__ double s_hx[4][PM_TS + 1], s_ky[4][PM_TS + 1];   // h_a, k_b
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long long pr = (long long)blockIdx.x * 4 + g;
-  const bool have = pr < npairs;
+  const long long p0 = ((long long)blockIdx.x * 4 + g) * seg;
+  if (p0 >= npairs) return;                       // whole wave; no workgroup barrier below
+  const long long p1 = p0 + seg < npairs ? p0 + seg : npairs;
   const double c = mp.cell;
   const int N = mp.N;
-  PeriodInfo p;
-  int i0 = 0, j0 = 0, a0 = 0, na = 0, b0 = 0, nb = 0;
-  if (have) {
+  double acc[PM_CELLS / 64];
+#pragma unroll
+  for (int u = 0; u < PM_CELLS / 64; ++u) acc[u] = 0.0;
+  int cur = pair_tile[p0];
+  long long run0 = p0;
+  auto flush = [&]() {
+    double* out = hm + run0 * PM_CELLS;
+#pragma unroll
+    for (int u = 0; u < PM_CELLS / 64; ++u) {
+      out[lane + 64 * u] = acc[u];
+      acc[u] = 0.0;
+    }
+  };
+  for (long long pr = p0; pr < p1; ++pr) {
     const int tl = pair_tile[pr];
+    if (tl != cur) {
+      flush();
+      cur = tl;
+      run0 = pr;
+    }
     const int d = d0 + tl / (nt * nt), rem = tl % (nt * nt);
-    i0 = (rem / nt) * PM_TS;
-    j0 = (rem % nt) * PM_TS;
-    p = pinfo[(int64_t)d * mp.T + pair_t[pr]];
+    const int i0 = (rem / nt) * PM_TS, j0 = (rem % nt) * PM_TS;
+    const PeriodInfo p = pinfo[(int64_t)d * mp.T + pair_t[pr]];
     // only the part of the tile under the stamp window needs corner values
     const int ja0 = max(j0, p.cc - p.H), ja1 = min(j0 + PM_TS - 1, p.cc + p.H);
     const int ib0 = max(i0, p.rc - p.H), ib1 = min(i0 + PM_TS - 1, p.rc + p.H);
-    a0 = ja0 - j0; na = ja1 - ja0 + 2;     // corners of columns ja0..ja1
-    b0 = ib0 - i0; nb = ib1 - ib0 + 2;     // corners of rows ib0..ib1
+    const int a0 = ja0 - j0, na = ja1 - ja0 + 2;     // corners of columns ja0..ja1
+    const int b0 = ib0 - i0, nb = ib1 - ib0 + 2;     // corners of rows ib0..ib1
     if (lane < na) {                 // column edges: x of the lower edge of column j0+a
       const int a = a0 + lane;
       const double x = (j0 + a - p.cc) * c - c / 2;
@@ -518,18 +566,16 @@ k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int 
       s_ky[g][b] = k;
       s_py[g][b] = pm_phi(-k);
     }
-  }
-  __syncthreads();
-  if (have) {
+    PM_WAVE_LDS_SYNC();
     for (int idx = lane; idx < na * nb; idx += 64) {
       const int b = b0 + idx / na, a = a0 + idx % na;
-      s_b[g][b * (PM_TS + 1) + a] = pm_bvu_phi(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
+      s_b[g][b * (PM_TS + 1) + a] = HIGH ? pm_bvu(mp.rule, s_hx[g][a], s_ky[g][b])
+                                         : pm_bvu_low_phi(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
     }
-  }
-  __syncthreads();
-  if (have) {
-    double* out = hm + pr * PM_CELLS;
-    for (int cell = lane; cell < PM_CELLS; cell += 64) {
+    PM_WAVE_LDS_SYNC();
+#pragma unroll
+    for (int u = 0; u < PM_CELLS / 64; ++u) {
+      const int cell = lane + 64 * u;
       const int li = cell / PM_TS, lj = cell % PM_TS;
       const int i = i0 + li, j = j0 + lj;
       const int ii = j - p.cc, jj = p.rc - i;
@@ -543,20 +589,30 @@ k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int 
         const double mass = ((ll - ul) - lu) + uu;
         v = __dmul_rn(p.hprob, mass);
       }
-      out[cell] = v;
+      acc[u] = __dadd_rn(acc[u], v);
     }
+    PM_WAVE_LDS_SYNC();              // the next pair overwrites the tables
   }
+  flush();
 }
 
-// per tile: add the records of its pairs in list (= period) order
+// per tile: add the run records of its pairs in list (= period) order.  Runs start at the tile's
+// first pair and at every multiple of `seg` inside its range (k_pair_masses).
 __global__ void __launch_bounds__(PM_CELLS)
 k_tile_accumulate(ModelParams mp, const long long* __restrict__ tcnt, const long long* __restrict__ toff,
-                  int d0, long long base, const double* __restrict__ hm, double* pmf /*[nd][N][N]*/) {
+                  int d0, long long base, int seg, const double* __restrict__ hm, double* pmf /*[nd][N][N]*/) {
   const int d = d0 + blockIdx.z, N = mp.N;
   const int64_t tile = ((int64_t)d * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  const long long n = tcnt[tile];
-  if (n == 0) return;
-  const double* rec = hm + (toff[tile] - base) * PM_CELLS + threadIdx.x;
+  const long long np = tcnt[tile];
+  if (np == 0) return;
+  const long long o = toff[tile] - base;                      // first pair of the tile in the chunk's list
+  const long long n = (o + np - 1) / seg - o / seg + 1;       // runs
+  const long long g0 = o / seg;
+  // k-th run record of this tile
+  auto at = [&](long long k) -> const double* {
+    const long long first = k == 0 ? o : (g0 + k) * seg;
+    return hm + first * PM_CELLS + threadIdx.x;
+  };
   double acc = 0.0;
   // sixteen loads in flight while the previous sixteen are added; the additions stay in list order
   long long q = 0;
@@ -564,19 +620,19 @@ k_tile_accumulate(ModelParams mp, const long long* __restrict__ tcnt, const long
   const long long nfull = n / 16 * 16;
   if (nfull > 0) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = rec[u * PM_CELLS];
+    for (int u = 0; u < 16; ++u) v[u] = *at(u);
   }
   for (; q < nfull; q += 16) {
     double w[16];
     const bool more = q + 16 < nfull;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = more ? rec[(q + 16 + u) * PM_CELLS] : 0.0;
+    for (int u = 0; u < 16; ++u) w[u] = more ? *at(q + 16 + u) : 0.0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc = __dadd_rn(acc, v[u]);
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = w[u];
   }
-  for (; q < n; ++q) acc = __dadd_rn(acc, rec[q * PM_CELLS]);
+  for (; q < n; ++q) acc = __dadd_rn(acc, *at(q));
   const int i = blockIdx.y * PM_TS + threadIdx.x / PM_TS, j = blockIdx.x * PM_TS + threadIdx.x % PM_TS;
   if (i < N && j < N) pmf[((int64_t)d * N + i) * N + j] = acc;
 }

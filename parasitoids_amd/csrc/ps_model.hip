@@ -227,11 +227,18 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
         hipLaunchKernelGGL(k_tile_fill, dim3(nt, nt, d1 - d0), dim3(256), 0, st, mp, m->pinfo.p, m->dinfo.p, m->tcnt.p,
                            m->toff.p, d0, base, m->pair_t.p, m->pair_tile.p);
         PS_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_pair_masses, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np,
-                           m->pair_t.p, m->pair_tile.p, m->hm.p);
+        // periods per record (PS_PM_SEG; 1 = one record per (tile, period) pair: sequential-loop sums)
+        static const int seg = getenv("PS_PM_SEG") ? std::max(1, atoi(getenv("PS_PM_SEG"))) : 8;
+        const long long nseg = (np + seg - 1) / seg;
+        if (mp.rule.high)
+          hipLaunchKernelGGL(k_pair_masses<true>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg,
+                             m->pair_t.p, m->pair_tile.p, m->hm.p);
+        else
+          hipLaunchKernelGGL(k_pair_masses<false>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg,
+                             m->pair_t.p, m->pair_tile.p, m->hm.p);
         PS_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_tile_accumulate, dim3(nt, nt, d1 - d0), dim3(PM_CELLS), 0, st, mp, m->tcnt.p, m->toff.p, d0,
-                           base, m->hm.p, m->pmf.p);
+                           base, seg, m->hm.p, m->pmf.p);
         PS_HIP(hipGetLastError());
       }
       d0 = d1;
