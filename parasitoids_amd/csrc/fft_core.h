@@ -377,7 +377,7 @@ PS_HD void bfly(cplx* x) {
   else if (R == 14) bfly_pfa<2, 7, DIR>(x);
   else if (R == 15) bfly_pfa<3, 5, DIR>(x);
   else if (R == 16) bfly16<DIR>(x);
-  else if (R == 18) bfly18<DIR>(x);
+  else if (R == 18) bfly_pfa<2, 9, DIR>(x);   // 2 x 9 coprime: no internal twiddles (32 operations fewer than the even/odd split of bfly18)
   else if (R == 20) bfly_pfa<4, 5, DIR>(x);
   else if (R == 21) bfly_pfa<3, 7, DIR>(x);
   else if (R == 24) bfly_pfa<3, 8, DIR>(x);

@@ -923,6 +923,10 @@ static int refft_if_flag(ps_solver* s, const double* rec, cplx* hat, int slot) {
 // by the register-resident row kernels (row passes 35-50 % faster) when that costs at most
 // 8 % more work
 static int fast_size(int Pref) {
+  if (const char* e = getenv("PS_FAST_SIZE")) {   // experiments: force the fast torus (must be >= the reference pad)
+    const int f = atoi(e);
+    if (f >= Pref) return f;
+  }
   int Pf = ps_next_fast_len(Pref);
   if (getenv("PS_NO_RS") == nullptr) {
     const int L = rs_next_size(Pref);
