@@ -97,6 +97,8 @@ def pmc_traffic(kernel_class):
     for e in entries:
         if not e['kernel'].startswith(names) or e.get('write_size_MB') is None:
             continue
+        if kernel_class.startswith('col_inv_a_x') and e['kernel'].startswith('void k_colfull<') and ', true, 0>' not in e['kernel']:
+            continue      # the forward / inverse / product instances of k_colfull are other classes
         if days is None and e.get('size_groups', 1) != 1:
             continue      # a kernel whose dispatches differ in size: not a single-day class
         if days and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
