@@ -140,7 +140,11 @@ int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t
                          const int32_t* row, const int32_t* col, const double* val);
 /* Run days [first, first+count) from the current state: per day
  * fftconv2 -> ifft2 -> statistics/flag -> (flagged) truncate + re-FFT, all enqueued on
- * the handle's stream without host synchronisation.  Day d's field is chain record d. */
+ * the handle's stream without host synchronisation.  Day d's field is chain record d.
+ * A run may be continued (first > 0 right after a run that ended at first) in PS_MODE_EXACT / FAST /
+ * FOLD.  PS_MODE_AUTO runs need a fresh state (ps_solver_set_state_*) before EVERY call: once a run
+ * has handed days over to its helpers the front solver's spectrum is void, and whether that happened
+ * depends on the data (PS_ERR_STATE "auto mode: set the state before every chain run" otherwise). */
 int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_scale,
                  int renorm);
 int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out); /* synchronises */

@@ -436,9 +436,10 @@ struct RsDual {
   static constexpr size_t fixed_bytes = 2 * (size_t)XH * sizeof(double) + (size_t)L * sizeof(cplx);
   static constexpr long spare = (long)160 * 1024 - (long)fixed_bytes;
   static constexpr int CAP = spare > 0 ? (int)(spare / (64 * (long)sizeof(cplx))) * 64 : 0;   // staged elements: whole 1 KB chunks
-  // (radix 20 and up: the butterflies do not fit the 168 registers of a 12-wave workgroup without scratch --
-  // a few spilled registers cost more than the second role gains, measured)
-  static constexpr bool ok = S::NTHR <= 384 && CAP >= 512 && S::RMAX <= 18;   // (<= 6 waves per role: their sums fit the slack words)
+  // (radix 21 and up -- and 20 x 15, 20 x 18 -- do not fit the 168 registers of a 12-wave workgroup: 8 to
+  // 100 spilled registers, which cost more than the second role gains; 20 x 14 and 20 x 16 spill 1-3)
+  static constexpr bool ok = S::NTHR <= 384 && CAP >= 512 &&
+                             (S::RMAX <= 18 || (S::RMAX == 20 && (R2 * R3 == 20 * 14 || R2 * R3 == 20 * 16)));   // (<= 6 waves per role: their sums fit the slack words)
   static constexpr size_t bytes = fixed_bytes + (size_t)CAP * sizeof(cplx);
   static_assert(S::T2 % 16 == 0 && S::T3 % 16 == 0, "half-pass offsets assume whole padding groups");
 };

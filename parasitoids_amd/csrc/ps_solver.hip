@@ -1630,7 +1630,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
 
 static int chain_run_body(ps_solver* s, int first, int count, double negval, double stat_scale, int renorm) {
   if (!s) return ps_fail(PS_ERR_BAD_ARG, "null solver");
-  if (!s->have_state) return ps_fail(PS_ERR_STATE, "chain_run before set_state");
+  if (!s->have_state)
+    return ps_fail(PS_ERR_STATE, s->auto_exact && s->auto_first >= 0
+                                     ? "auto mode: set the state before every chain run (the previous run handed days over to the "
+                                       "exact-torus helpers, the front solver's spectrum is void)"
+                                     : "chain_run before set_state");
   if (!s->kernels_on_device || first < 0 || count < 0 || first + count > s->nk)
     return ps_fail(PS_ERR_STATE, "chain_run: days [%d,%d) not uploaded (nk=%d)", first, first + count, s->nk);
   PS_HIP(hipSetDevice(s->device));

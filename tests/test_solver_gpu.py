@@ -314,6 +314,19 @@ def test_auto_mode_routes(hip_lib):
             outs.append([s.dense(0, d) for d in range(nd)])
         for d in range(nd):      # run 2 and 3 both start from the remembered hint: identical
             assert np.array_equal(outs[1][d], outs[2][d])
+        # a split run: continuing behind a hand-over needs a fresh state in this mode (the header says
+        # so); behind a clean first part it simply continues
+        s.set_state(state)
+        s.run_chain(0, nd // 2, renorm=True)
+        if expect_fold and s.auto_info()[0] >= 0:
+            from parasitoids_amd import _lib as L
+            with pytest.raises(L.HipError, match='set the state before every chain run') as ei:
+                s.run_chain(nd // 2, nd - nd // 2, renorm=True)
+            assert ei.value.code == L.PS_ERR_STATE
+        else:
+            s.run_chain(nd // 2, nd - nd // 2, renorm=True)
+            for d in range(nd):
+                np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13)
         s.close()
 
 
