@@ -437,7 +437,8 @@ struct RsDual {
   static constexpr long spare = (long)160 * 1024 - (long)fixed_bytes;
   static constexpr int CAP = spare > 0 ? (int)(spare / (64 * (long)sizeof(cplx))) * 64 : 0;   // staged elements: whole 1 KB chunks
   // (radix 21 and up -- and 20 x 15, 20 x 18 -- do not fit the 168 registers of a 12-wave workgroup: 8 to
-  // 100 spilled registers, which cost more than the second role gains; 20 x 14 and 20 x 16 spill 1-3)
+  // 100 spilled registers, which cost more than the second role gains; 20 x 14 and 20 x 16 spill 1-4,
+  // measured still ahead of the single-role pass: 8.32 -> 7.78 ms per 30-day stack at 5120)
   static constexpr bool ok = S::NTHR <= 384 && CAP >= 512 &&
                              (S::RMAX <= 18 || (S::RMAX == 20 && (R2 * R3 == 20 * 14 || R2 * R3 == 20 * 16)));   // (<= 6 waves per role: their sums fit the slack words)
   static constexpr size_t bytes = fixed_bytes + (size_t)CAP * sizeof(cplx);
