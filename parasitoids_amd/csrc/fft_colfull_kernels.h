@@ -231,9 +231,9 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
           if (q > qlo || j + q * S::T3 >= a.pad_row0) pe += x[q].x * x[q].x + x[q].y * x[q].y;
         }
       }
-      for (int off = 32; off > 0; off >>= 1) pe += __shfl_down(pe, off);
+      pe = ps_wave_sum(pe);
       double* red = ex + Y::XW;
-      if ((j & 63) == 0) red[j >> 6] = pe;
+      if ((j & 63) == 63) red[j >> 6] = pe;
       __syncthreads();
       if (j == 0) {
         double e = 0.0;
@@ -638,8 +638,8 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
           if (q > qlo || j + q * S::T3 >= a.pad_row0) pe += x[q].x * x[q].x + x[q].y * x[q].y;
         }
       }
-      for (int off = 32; off > 0; off >>= 1) pe += __shfl_down(pe, off);
-      if (lane == 0) exh[D::XH - 8 + wave] = pe;
+      pe = ps_wave_sum(pe);
+      if (lane == 63) exh[D::XH - 8 + wave] = pe;
     }
     if (role == 1) PS_WAIT_VM0();                          // this wave's share of the next kernel column has landed
     PS_BAR_LDS();                                          // product and staging visible; exchange buffers free

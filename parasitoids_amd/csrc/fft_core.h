@@ -661,3 +661,46 @@ PS_HD int row_phys(const FftProg& P, int i) {
 }
 // LDS elements one row-mode transform occupies
 PS_HD int row_pitch(const FftProg& P) { return P.La * P.Lbp; }
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------ wave reductions
+// Sum / maximum over the 64 lanes of a wave through DPP (row-internal permutes, then the two
+// row broadcasts of wave64): VALU-speed moves instead of the ds_bpermute round trips __shfl_down
+// compiles to -- 18 dependent LDS-pipe operations per double reduced, 0.8 us per row pair in the
+// inverse row pass (measured by leaving them out).  The result is valid in LANE 63 only.  Fixed
+// combination order: the same on every run and in every kernel that uses it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double ps_dpp_f64(double v, double ident) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(ident), lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ps_wave_sum(double v) {       // -> lane 63
+  v += ps_dpp_f64<0xB1, 0xf>(v, 0.0);    // quad_perm [1,0,3,2]
+  v += ps_dpp_f64<0x4E, 0xf>(v, 0.0);    // quad_perm [2,3,0,1]
+  v += ps_dpp_f64<0x141, 0xf>(v, 0.0);   // row_half_mirror
+  v += ps_dpp_f64<0x140, 0xf>(v, 0.0);   // row_mirror: every lane of a row holds the row's sum
+  v += ps_dpp_f64<0x142, 0xa>(v, 0.0);   // row_bcast15 into rows 1 and 3
+  v += ps_dpp_f64<0x143, 0xc>(v, 0.0);   // row_bcast31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double ps_wave_max0(double v) {      // values >= 0; -> lane 63
+  v = fmax(v, ps_dpp_f64<0xB1, 0xf>(v, 0.0));
+  v = fmax(v, ps_dpp_f64<0x4E, 0xf>(v, 0.0));
+  v = fmax(v, ps_dpp_f64<0x141, 0xf>(v, 0.0));
+  v = fmax(v, ps_dpp_f64<0x140, 0xf>(v, 0.0));
+  v = fmax(v, ps_dpp_f64<0x142, 0xa>(v, 0.0));
+  v = fmax(v, ps_dpp_f64<0x143, 0xc>(v, 0.0));
+  return v;
+}
+__device__ __forceinline__ int ps_wave_sum_i32(int v) {         // -> lane 63
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+#endif

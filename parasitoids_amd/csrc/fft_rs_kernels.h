@@ -90,8 +90,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   // The barrier is unconditional: the NP row pairs of a workgroup share it, and a pair that
   // returns here simply stops counting for the later ones.
   if (pad_only) {   // uniform per row pair
-    for (int off = 32; off > 0; off >>= 1) energy += __shfl_down(energy, off);
-    if (lane == 0) red[wave] = energy;
+    energy = ps_wave_sum(energy);
+    if (lane == 63) red[wave] = energy;
   }
   __syncthreads();
   if (pad_only) {
@@ -143,16 +143,14 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
       }
     }
   }
-  // deterministic block reduction (fixed shuffle tree, then waves in order)
-  for (int off = 32; off > 0; off >>= 1) {
-    sa += __shfl_down(sa, off);
-    sb += __shfl_down(sb, off);
-    ca += __shfl_down(ca, off);
-    cb += __shfl_down(cb, off);
-    pmax = fmax(pmax, __shfl_down(pmax, off));
-  }
+  // deterministic block reduction (fixed DPP tree, then waves in order)
+  sa = ps_wave_sum(sa);
+  sb = ps_wave_sum(sb);
+  ca = ps_wave_sum_i32(ca);
+  cb = ps_wave_sum_i32(cb);
+  pmax = ps_wave_max0(pmax);
   double* redm = red + 4 * NW;
-  if (lane == 0) {
+  if (lane == 63) {
     red[wave * 4 + 0] = sa;
     red[wave * 4 + 1] = sb;
     red[wave * 4 + 2] = (double)ca;
@@ -289,8 +287,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
       }
     }
     if (pad_only) {   // uniform per workgroup
-      for (int off = 32; off > 0; off >>= 1) energy += __shfl_down(energy, off);
-      if (lane == 0) red[wave] = energy;
+      energy = ps_wave_sum(energy);
+      if (lane == 63) red[wave] = energy;
     }
     PS_BAR_LDS();                               // staging is free again
     if (u + (int)gridDim.x < units) prefetch(u + (int)gridDim.x);
@@ -346,15 +344,13 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
         }
       }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      sa += __shfl_down(sa, off);
-      sb += __shfl_down(sb, off);
-      ca += __shfl_down(ca, off);
-      cb += __shfl_down(cb, off);
-      pmax = fmax(pmax, __shfl_down(pmax, off));
-    }
+    sa = ps_wave_sum(sa);
+    sb = ps_wave_sum(sb);
+    ca = ps_wave_sum_i32(ca);
+    cb = ps_wave_sum_i32(cb);
+    pmax = ps_wave_max0(pmax);
     double* redm = red + 4 * NW;
-    if (lane == 0) {
+    if (lane == 63) {
       red[wave * 4 + 0] = sa;
       red[wave * 4 + 1] = sb;
       red[wave * 4 + 2] = (double)ca;
