@@ -522,16 +522,27 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
       } else {
         int a1, b1, a2, b2;
         live_of(slot, a1, b1, a2, b2);
-        const int len1 = b1 - a1;
-        const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)slot * a.src_dstride + (int64_t)c * L;
+        const int len1 = b1 - a1, len2 = b2 - a2;
+        if (len1 + len2 <= D::CAP) {     // uniform; the usual case: every live row was staged
 #pragma unroll
-        for (int q = 0; q < R1; ++q) {
-          const int n = j + q * S::T1;
-          x[q] = make_double2(0.0, 0.0);
-          int e = -1;
-          if (n >= a1 && n < b1) e = n - a1;
-          else if (n >= a2 && n < b2) e = len1 + (n - a2);
-          if (e >= 0) x[q] = e < D::CAP ? stage[e] : sc[n];
+          for (int q = 0; q < R1; ++q) {
+            const int n = j + q * S::T1;
+            const unsigned d1 = (unsigned)(n - a1), d2 = (unsigned)(n - a2);
+            const bool in1 = d1 < (unsigned)len1, in2 = d2 < (unsigned)len2;
+            const cplx v = stage[in1 ? d1 : (in2 ? len1 + d2 : 0u)];
+            x[q] = (in1 || in2) ? v : make_double2(0.0, 0.0);
+          }
+        } else {
+          const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)slot * a.src_dstride + (int64_t)c * L;
+#pragma unroll
+          for (int q = 0; q < R1; ++q) {
+            const int n = j + q * S::T1;
+            x[q] = make_double2(0.0, 0.0);
+            int e = -1;
+            if (n >= a1 && n < b1) e = n - a1;
+            else if (n >= a2 && n < b2) e = len1 + (n - a2);
+            if (e >= 0) x[q] = e < D::CAP ? stage[e] : sc[n];
+          }
         }
       }
       bfly<R1, PS_FWD>(x);

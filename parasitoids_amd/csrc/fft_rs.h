@@ -109,8 +109,15 @@ __device__ __forceinline__ void rs_bar() {
 
 // stages 2 and 3 with both exchanges; on entry x holds the stage-1 OUTPUT of thread j,
 // on exit the stage-3 output (natural index j + q' T3) of thread j < T3.
-template <class S, int R1, int R2, int R3, int DIR, bool RAW = false>
-__device__ __forceinline__ void rs_tail(cplx* x, double* ex, const int j, const cplx w2, const cplx w3) {
+struct RsNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `hook` runs in the second stage's butterfly interval, the longest stretch without a barrier:
+// threads beyond T2 have nothing to do there (the persistent row kernel's last wave finishes the
+// previous pair's statistics in it)
+template <class S, int R1, int R2, int R3, int DIR, bool RAW = false, class Hook = RsNoHook>
+__device__ __forceinline__ void rs_tail(cplx* x, double* ex, const int j, const cplx w2, const cplx w3,
+                                        const Hook& hook = Hook()) {
   if (j < S::T1) rs_put<R1, 0>(ex, S::x1_w(j), 1, x);
   rs_bar<RAW>();
   if (j < S::T2) rs_get<R2, 0>(ex, S::x_r(j), S::X1_RS, x);
@@ -118,6 +125,7 @@ __device__ __forceinline__ void rs_tail(cplx* x, double* ex, const int j, const 
   if (j < S::T1) rs_put<R1, 1>(ex, S::x1_w(j), 1, x);
   rs_bar<RAW>();
   if (j < S::T2) rs_get<R2, 1>(ex, S::x_r(j), S::X1_RS, x);
+  hook();
   if (j < S::T2) rs_stage<R2, DIR>(x, w2, true);
   rs_bar<RAW>();
   if (j < S::T2) rs_put<R2, 0>(ex, S::x2_w(j), 17, x);

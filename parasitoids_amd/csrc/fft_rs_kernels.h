@@ -18,7 +18,7 @@ template <int R1, int R2, int R3>
 struct RsInvLds {
   using S = Rs<R1, R2, R3>;
   static constexpr int XW = (S::XWORDS + 15) & ~15;
-  static constexpr int RED = 8 * (S::NTHR / 64);
+  static constexpr int RED = 16 * (S::NTHR / 64);   // two sets of 5 wave partials (k_row_inv_rsp defers the finalisation) + energy
   static constexpr size_t bytes(int np) { return (size_t)np * (XW + RED) * sizeof(double); }
 };
 
@@ -125,8 +125,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
         const bool ka = !(ta < a.negval), kb = !(tb < a.negval);
         sa += ka ? ta : 0.0;
         sb += kb ? tb : 0.0;
-        ca += ka ? 1 : 0;
-        cb += kb ? 1 : 0;
+        ca += __popcll(__ballot(ka));     // per wave, on the scalar unit
+        cb += __popcll(__ballot(kb));
       } else {
         const bool in = i < uN;
         const bool ina = in && dom_a, inb = in && dom_b;
@@ -134,8 +134,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
         const bool ka = ina && !(ta < a.negval), kb = inb && !(tb < a.negval);
         sa += ka ? ta : 0.0;
         sb += kb ? tb : 0.0;
-        ca += ka ? 1 : 0;
-        cb += kb ? 1 : 0;
+        ca += __popcll(__ballot(ka));
+        cb += __popcll(__ballot(kb));
         pmax = fmax(pmax, ina ? 0.0 : va);
         pmax = fmax(pmax, (inb || !hasb) ? 0.0 : vb);
         if (ina) reca[i] = va;
@@ -146,8 +146,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   // deterministic block reduction (fixed DPP tree, then waves in order)
   sa = ps_wave_sum(sa);
   sb = ps_wave_sum(sb);
-  ca = ps_wave_sum_i32(ca);
-  cb = ps_wave_sum_i32(cb);
+  ca = __builtin_amdgcn_readfirstlane(ca);   // the same in every lane that took part (lane 0 did if any did)
+  cb = __builtin_amdgcn_readfirstlane(cb);
   pmax = ps_wave_max0(pmax);
   double* redm = red + 4 * NW;
   if (lane == 63) {
@@ -216,7 +216,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
   constexpr int NCH = Z::HS / 64;              // 1 KB chunks per staged row
   constexpr int H = L / 2 + 1;
   double* ex = reinterpret_cast<double*>(ps_lds_raw);
-  double* red = ex + Y::XW;      // 5 * NW doubles
+  double* red = ex + Y::XW;      // two sets of 5 * NW wave partials, then NW energy sums
+  double* ered = red + 10 * NW;
   cplx* stA = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);
   cplx* stB = stA + Z::HS;
   const int j0 = threadIdx.x, lane = j0 & 63, wave = j0 >> 6;
@@ -246,6 +247,34 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
       }
     }
   };
+
+  // The row statistics of a pair (sums of the wave partials, two stores, the pre-checked atomicMax of
+  // the pad maximum) used to end its round on one thread while everybody waited at the next barrier.
+  // They are now written by the last wave's last lane -- idle in the first stage -- one round LATER,
+  // behind that round's first barrier, out of the other waves' way (partials double-buffered).
+  auto finalize = [&](int fb, int fra, const double* part) {
+    const double* partm = part + 4 * NW;
+    double ta = 0, tb = 0, na = 0, nbb = 0, m = 0;
+    for (int w = 0; w < NW; ++w) {
+      ta += part[w * 4 + 0];
+      tb += part[w * 4 + 1];
+      na += part[w * 4 + 2];
+      nbb += part[w * 4 + 3];
+      m = fmax(m, partm[w]);
+    }
+    const int frb = fra + 1;
+    double* rowsum = a.rowsum + (int64_t)fb * a.stat_bstride;
+    long long* rowcnt = a.rowcnt + (int64_t)fb * a.stat_bstride;
+    if (fra < a.N) { rowsum[fra] = ta; rowcnt[fra] = (long long)na; }
+    if (frb < a.N) { rowsum[frb] = tb; rowcnt[frb] = (long long)nbb; }
+    unsigned long long* pm = a.padmax + fb;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m > a.pad_floor && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(pm, bits);
+  };
+  bool pend = false;             // uniform: a finished pair whose partials wait in red[(par ^ 1) * 5 NW ...]
+  int pend_b = 0, pend_ra = 0, par = 0;
+  const bool finalizer = j0 == S::NTHR - 1;
 
   int u = (int)blockIdx.x;
   if (u < units) prefetch(u);
@@ -288,21 +317,29 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
     }
     if (pad_only) {   // uniform per workgroup
       energy = ps_wave_sum(energy);
-      if (lane == 63) red[wave] = energy;
+      if (lane == 63) ered[wave] = energy;
     }
     PS_BAR_LDS();                               // staging is free again
     if (u + (int)gridDim.x < units) prefetch(u + (int)gridDim.x);
     if (pad_only) {
       // Parseval bound on the largest value of a pad-only pair (see k_row_inv)
       double e = 0.0;
-      for (int w = 0; w < NW; ++w) e += red[w];
+      for (int w = 0; w < NW; ++w) e += ered[w];
       if (sqrt(2.0 * (double)a.P * e) * a.scale < a.pad_floor) {
         PS_WAIT_VM0();
         continue;
       }
     }
     if (j < S::T1) bfly<R1, PS_INV>(x);
-    rs_tail<S, R1, R2, R3, PS_INV, true>(x, ex, j, w2, w3);
+    // (the previous pair's partials were complete before this round's first barrier)
+    const bool fin = pend && finalizer;
+    const int fb = pend_b, fra = pend_ra;
+    const double* fpart = red + (par ^ 1) * 5 * NW;
+    auto hook = [&]() {
+      if (fin) finalize(fb, fra, fpart);
+    };
+    rs_tail<S, R1, R2, R3, PS_INV, true>(x, ex, j, w2, w3, hook);
+    pend = false;
     // the prefetch has had the whole transform to land; waiting for it HERE (before this pair's
     // stores are issued) keeps the stores out of the wait at the top of the next round
     PS_WAIT_VM0();
@@ -327,16 +364,16 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
           const bool ka = !(ta < a.negval), kb = !(tb < a.negval);
           sa += ka ? ta : 0.0;
           sb += kb ? tb : 0.0;
-          ca += ka ? 1 : 0;
-          cb += kb ? 1 : 0;
+          ca += __popcll(__ballot(ka));     // per wave, on the scalar unit
+          cb += __popcll(__ballot(kb));
         } else {
           const bool in = i < uN;
           const bool ina = in && dom_a, inb = in && dom_b;
           const bool ka = ina && !(ta < a.negval), kb = inb && !(tb < a.negval);
           sa += ka ? ta : 0.0;
           sb += kb ? tb : 0.0;
-          ca += ka ? 1 : 0;
-          cb += kb ? 1 : 0;
+          ca += __popcll(__ballot(ka));
+          cb += __popcll(__ballot(kb));
           pmax = fmax(pmax, ina ? 0.0 : va);
           pmax = fmax(pmax, (inb || !hasb) ? 0.0 : vb);
           if (ina) reca[i] = va;
@@ -346,38 +383,26 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
     }
     sa = ps_wave_sum(sa);
     sb = ps_wave_sum(sb);
-    ca = ps_wave_sum_i32(ca);
-    cb = ps_wave_sum_i32(cb);
+    ca = __builtin_amdgcn_readfirstlane(ca);   // the same in every lane that took part (lane 0 did if any did)
+    cb = __builtin_amdgcn_readfirstlane(cb);
     pmax = ps_wave_max0(pmax);
-    double* redm = red + 4 * NW;
+    double* part = red + par * 5 * NW;
     if (lane == 63) {
-      red[wave * 4 + 0] = sa;
-      red[wave * 4 + 1] = sb;
-      red[wave * 4 + 2] = (double)ca;
-      red[wave * 4 + 3] = (double)cb;
-      redm[wave] = pmax;
+      part[wave * 4 + 0] = sa;
+      part[wave * 4 + 1] = sb;
+      part[wave * 4 + 2] = (double)ca;
+      part[wave * 4 + 3] = (double)cb;
+      part[4 * NW + wave] = pmax;
     }
-    PS_BAR_LDS();
-    if (j == 0) {
-      double ta = 0, tb = 0, na = 0, nbb = 0, m = 0;
-      for (int w = 0; w < NW; ++w) {
-        ta += red[w * 4 + 0];
-        tb += red[w * 4 + 1];
-        na += red[w * 4 + 2];
-        nbb += red[w * 4 + 3];
-        m = fmax(m, redm[w]);
-      }
-      double* rowsum = a.rowsum + (int64_t)b * a.stat_bstride;
-      long long* rowcnt = a.rowcnt + (int64_t)b * a.stat_bstride;
-      if (ra < a.N) { rowsum[ra] = ta; rowcnt[ra] = (long long)na; }
-      if (rb < a.N) { rowsum[rb] = tb; rowcnt[rb] = (long long)nbb; }
-      unsigned long long* pm = a.padmax + b;
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-      if (m > a.pad_floor && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(pm, bits);
-    }
+    pend = true;
+    pend_b = b;
+    pend_ra = ra;
+    par ^= 1;
   }
+  PS_BAR_LDS();
+  if (pend && finalizer) finalize(pend_b, pend_ra, red + (par ^ 1) * 5 * NW);
 }
+
 
 
 // ------------------------------------------------------------ forward rows
