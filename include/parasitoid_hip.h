@@ -193,7 +193,7 @@ int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx
  * 6 the three predicated passes of the flag-conditional re-FFT (no-ops when the flag is clear),
  * 7/8/9 class 3 for 2/4/8 consecutive days in one launch,
  * 10/11/12 class 5 for the 2/4/8 days of a chained group in one launch (full-column pipeline),
- * 13/14 classes 3/5 for any other number of days per launch (up to 16; a solver whose previous run
+ * 13/14 classes 3/5 for any other number of days per launch (up to 32; a solver whose previous run
  *       raised no flag opens with such windows) -- ps_prof_read_days gives the grid-days they covered,
  * 15 the three short launches for the columns taken out of a chained pass (its thin last round) */
 #define PS_PROF_NCLS 16

@@ -110,7 +110,7 @@ struct RowInvArgs {
   // fetches nor tests them; nullptr = unknown
   const int* pad_quiet;
   int nrec;                   // > 0: batch entry b writes rec_multi[b] (the days of a chained group)
-  double* rec_multi[16];      // = PS_MAX_GROUP_DAYS (ps_solver.hip)
+  double* rec_multi[32];      // = PS_MAX_GROUP_DAYS (ps_solver.hip)
   FftProg prog;
 };
 

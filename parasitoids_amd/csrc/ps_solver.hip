@@ -149,7 +149,7 @@ enum { PS_PROF_ROW_FWD = 0, PS_PROF_COL_FWD_A = 1, PS_PROF_COL_FWD_B = 2, PS_PRO
        PS_PROF_COL_INV_AN = 13,   // any other number of chained days in one launch (days counted in prof_days)
        PS_PROF_ROW_INVN = 14,
        PS_PROF_COL_TAIL = 15 };   // the three launches for the columns taken out of a chained pass (conv_inv_multi)
-#define PS_MAX_GROUP_DAYS 16       // most days one chained full-column pass / batched row pass takes
+#define PS_MAX_GROUP_DAYS 32       // most days one chained full-column pass / batched row pass takes
 
 struct ColPass {
   DevPlan* plan;
@@ -1721,7 +1721,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
   if (getenv("PS_NO_SPECULATION")) s->speculate = false;
   // A solver whose previous run went through without a flag (sampler chains and ensemble members re-run
   // the same solver on new kernels) does not feel its way 2, 4, 8, ...: it opens with windows of up to
-  // PS_MAX_GROUP_DAYS days, equal parts of the run (30 days: 15 + 15), each ONE chained full-column
+  // PS_MAX_GROUP_DAYS = 32 days (a 30-day run: one window), each ONE chained full-column
   // pass and ONE row launch.  A flag inside such a window is handled like any other (days behind
   // it are redone); the hint is then gone.  PS_NO_WINDOW_HINT=1: A/B knob.
   const int hint = s->noflag_hint;
@@ -1773,8 +1773,15 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
   }
   PS_TRY(ensure_spectrum(s));
   if (s->speculate && s->tpipe && colfull_chains(s) && hint >= count && count >= 4 && getenv("PS_NO_WINDOW_HINT") == nullptr) {
-    const int parts = (count + PS_MAX_GROUP_DAYS - 1) / PS_MAX_GROUP_DAYS;
-    s->spec_window = (count + parts - 1) / parts;
+    // windows of up to PS_MAX_GROUP_DAYS days, the whole run if it fits.  Measured on the 30-day stack
+    // (PS_FIRST_WINDOW): 6 / 8 / 10 / 15 days first and the rest behind -- with the later windows'
+    // kernel transforms on the low-priority stream -- 7.98 ms each, one 30-day window 7.84: the idle
+    // slot of a second chained pass and the launches saved outweigh the 0.2 ms of kernel transforms
+    // that are no longer hidden.
+    const char* fw = getenv("PS_FIRST_WINDOW");   // tuning knob
+    int w0 = fw ? atoi(fw) : count;
+    w0 = std::max(2, std::min(std::min(w0, count), PS_MAX_GROUP_DAYS));
+    s->spec_window = w0;
     hinted = true;
   }
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
@@ -1872,7 +1879,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
         q.push_back(Win{d, w, nev & 1});
         ++nev;
         d += w;
-        s->spec_window = std::min(64, 2 * s->spec_window);
+        s->spec_window = hinted ? PS_MAX_GROUP_DAYS : std::min(64, 2 * s->spec_window);
       }
       if (q.empty()) break;
       const Win x = q.front();

@@ -475,7 +475,7 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
 
 
 def test_window_hint_changes_nothing(hip_lib, monkeypatch):
-    """A solver whose previous chain raised no flag opens its next run with windows of up to 16
+    """A solver whose previous chain raised no flag opens its next run with windows of up to 32
     days (one chained full-column pass + one row launch each: `col_inv_a_xn`, `row_inv_xn`) instead
     of 2, 4, 8, ...  Same records, flags and statistics bit for bit -- for a clean chain re-run, and
     for a re-run on a state that DOES raise a flag inside the first long window (the days behind
@@ -503,7 +503,7 @@ def test_window_hint_changes_nothing(hip_lib, monkeypatch):
     s.set_kernels(kernels)
     a = run(s, centre)                     # windows 2, 4, 8, 6: nothing hinted
     assert not any(f for f, _, _, _ in a[1])
-    b = run(s, centre)                     # hinted: 10 + 10
+    b = run(s, centre)                     # hinted: one 20-day window
     assert b[2] == nd and b[3] == nd, b[2:]
     assert a[1] == b[1]
     for x, y in zip(a[0], b[0]):
