@@ -25,7 +25,7 @@ for L in SIZES:
         assert d['config']['fft_len'] == L, (L, d['config'])
         row = {'ms_per_step': d['ms_per_step'], 'ns_per_elem_day': d['ms_per_step'] * 1e6 / 30 / (L * L)}
         for k, v in d['kernels'].items():
-            nd = int(k.rsplit('_x', 1)[1]) if '_x' in k else 1
+            nd = v.get('days_per_launch') or (int(k.rsplit('_x', 1)[1]) if '_x' in k and k.rsplit('_x', 1)[1].isdigit() else 1)
             row[k] = round(v['avg_ms'] * 1e6 / nd / (L * L), 4)
         out['%d_tp%s' % (L, tp)] = row
         print(L, 'tpipe' if tp == '1' else 'tiled', json.dumps(row), flush=True)
