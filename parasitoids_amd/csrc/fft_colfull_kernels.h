@@ -410,7 +410,7 @@ static __global__ void k_prefix_cols(cplx* state, cplx* khat, int L, int ncols, 
 //                 order) -> inverse transform -> the row-major intermediate of day s-1
 //   role 1 ("B"): slot s < nd: kernel column of day s -> forward transform -> state column *= it
 // nd + 1 slots for nd days (A idles in the first, B in the last: the state column is loaded /
-// stored there), which is why only long groups come here (a solver whose previous run raised no
+// stored there, off the other role's path), which is why only long groups come here (a solver whose previous run raised no
 // flag opens with windows of up to 16 days).  Same butterflies, twiddles and products in the same
 // order as the single-role pass: results are bit-identical.
 //
@@ -495,11 +495,9 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
     }
   };
 
-  // prologue: state column -> LDS (role A, coalesced), kernel column of day 0 -> staging (role B)
-  if (role == 0) {
-#pragma unroll 7
-    for (int k = j0; k < L; k += S::NTHR) sst[k] = st[k];
-  } else {
+  // prologue: kernel column of day 0 -> staging (role B); role A brings the state column in during
+  // slot 0, where it has no transform to run (role B needs it only for the product at the slot's end)
+  if (role == 1) {
     stage_column(0);
     PS_WAIT_VM0();
   }
@@ -515,6 +513,10 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
     // ---- first-stage inputs.  Role A's inverse transform runs through the FORWARD code on
     // conjugated data (inverse(x) == conj(forward(conj(x))) bit for bit, see rs_stage): one
     // transform body for both roles, one set of data registers.
+    if (role == 0 && slot == 0) {        // state column -> LDS, coalesced
+#pragma unroll 7
+      for (int k = j; k < L; k += S::NTHR) sst[k] = st[k];
+    }
     if (act && j < S::T1) {
       if (role == 0) {
 #pragma unroll
