@@ -415,20 +415,28 @@ def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
     R, K, nd = 150, 101, 12
     N = 2 * R + 1
     _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(3.0, 6.0), shift=4)
+    # ONE solver for the three states, each twice in a row: what a run remembers of the one before
+    # (first unclean day, first helper) belongs to a different state half of the time.  Exact either way.
+    s = None
     for start in (230, 262, 285):
         state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
         ref, trace = [state], {}
         OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, np.array([K, K]), trace=trace)
-        s = hip_lib.HipSolve(state, [K, K], mode='auto', chain_only=True)
-        s.set_kernels(kernels)
-        s.run_chain(renorm=True)
-        st = s.chain_stats(0, nd)
-        seen |= set(int(v) for v in s.auto_route(0, nd))
-        for d in range(nd):
-            np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13)
-            assert bool(st[d].flag) == bool(trace['flags'][d]), (start, d)
-            assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
-        s.close()
+        if s is None:
+            s = hip_lib.HipSolve(state, [K, K], mode='auto', chain_only=True)
+            s.set_kernels(kernels)
+        routes = []
+        for rep in range(2):
+            s.set_state(state)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, nd)
+            routes.append(s.auto_route(0, nd))
+            seen |= set(int(v) for v in routes[-1])
+            for d in range(nd):
+                np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13)
+                assert bool(st[d].flag) == bool(trace['flags'][d]), (start, rep, d)
+                assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
+    s.close()
     assert seen >= {0, 1, 2}, seen        # clean prefix, wide helper and fold child all took days
 
 
