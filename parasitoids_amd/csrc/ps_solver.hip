@@ -191,6 +191,9 @@ struct ps_solver {
   hipStream_t stream2 = nullptr;
   hipEvent_t kt_ev = nullptr, kt_ev0 = nullptr;
   int kt_from = -1;
+  // auto mode, front solver: kernels from this day on are transformed only if the run gets there
+  // (the previous run left the front at its first unclean day); -1 = nothing pending
+  int kt_lazy_from = -1, kt_lazy_c0 = 0, kt_lazy_cn = 0;
   unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
   int hflags_n = 0;
   int rs_r2 = 0, rs_r3 = 0;   // register-resident row kernels (fft_rs.h) for Pf = 16 * rs_r2 * rs_r3, or 0
@@ -1288,7 +1291,7 @@ static bool day_is_compact(const ps_solver* s, int d) {
 // transform `count` kernels starting at day `first` into Bhat[0..count)
 // The transforms go to slots [slot0, slot0 + count) of buffers sized for `total` slots (a chunk
 // transformed in two parts: the second part on the second stream).
-static int transform_kernels(ps_solver* s, int first, int count, int slot0 = 0, int total = -1) {
+static int transform_kernels(ps_solver* s, int first, int count, int slot0, int total) {
   const int K = s->Kmax, M = K / 2;
   const size_t spec = (size_t)s->Pf * s->ld;
   if (total < 0) total = count;
@@ -1337,7 +1340,13 @@ static int transform_kernels(ps_solver* s, int first, int count, int slot0 = 0, 
 }
 
 // main stream: wait for the second stream's kernel transforms before day `d` is used
+static int transform_kernels(ps_solver* s, int first, int count, int slot0 = 0, int total = -1);
 static int kernels_ready(ps_solver* s, int d) {
+  if (s->kt_lazy_from >= 0 && d >= s->kt_lazy_from) {
+    const int from = s->kt_lazy_from, done = from - s->kt_lazy_c0;
+    s->kt_lazy_from = -1;
+    PS_TRY(transform_kernels(s, from, s->kt_lazy_cn - done, done, s->kt_lazy_cn));
+  }
   if (s->kt_from >= 0 && d >= s->kt_from) {
     PS_HIP(hipStreamWaitEvent(s->stream, s->kt_ev, 0));
     s->kt_from = -1;
@@ -1625,6 +1634,7 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     (void)hipStreamWaitEvent(s->stream, s->kt_ev, 0);
     s->kt_from = -1;
   }
+  if (s) s->kt_lazy_from = -1;   // kernels this run never reached stay untransformed
   return rc;
 }
 
@@ -1792,7 +1802,9 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // eleventh round occupies 33 of them -- instead of 0.2 ms up front.
     const char* kts = getenv("PS_KT_SPLIT");                     // A/B knob (per run: tests flip it): 0 = off
     const int split_days = kts ? atoi(kts) : (hinted ? s->spec_window : 14);   // = the first window(s)
-    if (s->tpipe && s->speculate && split_days > 0 && cn >= split_days + (hinted ? 4 : 8)) {
+    const bool lazy_tail = s->auto_exact && hint_abs >= c0 && hint_abs + 2 < c0 + cn &&
+                           getenv("PS_NO_LAZY_KT") == nullptr;   // see the branch below (A/B knob)
+    if (!lazy_tail && s->tpipe && s->speculate && split_days > 0 && cn >= split_days + (hinted ? 4 : 8)) {
       if (!s->stream2) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = numerically greatest = lowest priority
@@ -1812,6 +1824,16 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       if (rc2 != PS_OK) return rc2;
       PS_HIP(hipEventRecord(s->kt_ev, s->stream2));
       s->kt_from = c0 + split_days;
+    } else if (lazy_tail) {
+      // the previous run handed over at day hint_abs: this one will most likely not need the front's
+      // spectra of the kernels behind it (29 kernels at 5600 points are 2.6 ms of a 47 ms Carnarvon
+      // chain, 17 at 1120 points a twentieth of a Bayes evaluation); kernels_ready transforms the
+      // rest if the run stays clean for longer
+      const int now = hint_abs + 2 - c0;
+      PS_TRY(transform_kernels(s, c0, now, 0, cn));
+      s->kt_lazy_from = c0 + now;
+      s->kt_lazy_c0 = c0;
+      s->kt_lazy_cn = cn;
     } else {
       PS_TRY(transform_kernels(s, c0, cn));
     }
