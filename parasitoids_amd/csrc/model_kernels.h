@@ -465,7 +465,7 @@ k_tile_count(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo
 __global__ void __launch_bounds__(256)
 k_tile_fill(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo* __restrict__ dinfo,
             const long long* __restrict__ tcnt, const long long* __restrict__ toff, int d0, long long base,
-            int* __restrict__ pair_t, int* __restrict__ pair_tile) {
+            long long cap, int* __restrict__ pair_t, int* __restrict__ pair_tile) {
   const int d = d0 + blockIdx.z, T = mp.T;
   const int i0 = blockIdx.y * PM_TS, j0 = blockIdx.x * PM_TS;
   const int64_t tile = ((int64_t)d * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -485,8 +485,10 @@ k_tile_fill(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo*
     for (int w = 0; w < wave; ++w) pos += s_wcnt[w];
     if (hit) {
       const long long o = out0 + pos + __popcll(m & ((1ull << lane) - 1ull));
-      pair_t[o] = t;
-      pair_tile[o] = (int)(tile - (int64_t)d0 * gridDim.y * gridDim.x);
+      if (o < cap) {   // (the lists were sized from the previous batch: an overflow is detected and redone)
+        pair_t[o] = t;
+        pair_tile[o] = (int)(tile - (int64_t)d0 * gridDim.y * gridDim.x);
+      }
     }
     nlist += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
     __syncthreads();
@@ -514,8 +516,10 @@ k_tile_fill(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo*
 // i.e. four resident waves per SIMD instead of three.
 template <bool HIGH>
 __global__ void __launch_bounds__(256, HIGH ? 2 : 4)   // common instance: 128 registers (2 spilled), four waves per SIMD
-k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int nt, long long npairs, int seg,
+k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int nt, long long npairs_, int seg,
+              const long long* __restrict__ np_dev,   // != nullptr: the real pair count (npairs_ = capacity of the lists)
               const int* __restrict__ pair_t, const int* __restrict__ pair_tile, double* __restrict__ hm) {
+  const long long npairs = np_dev ? (*np_dev < npairs_ ? *np_dev : npairs_) : npairs_;
   __shared__ double s_b[4][PM_NC];
   __shared__ double s_px[4][PM_TS + 1], s_py[4][PM_TS + 1];   // Phi(-h_a), Phi(-k_b)
   __shared__ double s_hx[4][PM_TS + 1], s_ky[4][PM_TS + 1];   // h_a, k_b
@@ -596,16 +600,24 @@ k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int 
   flush();
 }
 
+// number of pairs of a batch = last offset + last count (device-side, so that the host does not
+// have to wait for the scan before it can enqueue the pair kernels)
+static __global__ void k_pair_total(const long long* __restrict__ toff, const long long* __restrict__ tcnt, long long ntot,
+                                    long long* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = toff[ntot - 1] + tcnt[ntot - 1];
+}
+
 // per tile: add the run records of its pairs in list (= period) order.  Runs start at the tile's
 // first pair and at every multiple of `seg` inside its range (k_pair_masses).
 __global__ void __launch_bounds__(PM_CELLS)
 k_tile_accumulate(ModelParams mp, const long long* __restrict__ tcnt, const long long* __restrict__ toff,
-                  int d0, long long base, int seg, const double* __restrict__ hm, double* pmf /*[nd][N][N]*/) {
+                  int d0, long long base, int seg, long long cap, const double* __restrict__ hm, double* pmf /*[nd][N][N]*/) {
   const int d = d0 + blockIdx.z, N = mp.N;
   const int64_t tile = ((int64_t)d * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   const long long np = tcnt[tile];
   if (np == 0) return;
   const long long o = toff[tile] - base;                      // first pair of the tile in the chunk's list
+  if (o + np > cap) return;                                   // beyond the lists' capacity: the batch is redone
   const long long n = (o + np - 1) / seg - o / seg + 1;       // runs
   const long long g0 = o / seg;
   // k-th run record of this tile

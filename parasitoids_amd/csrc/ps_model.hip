@@ -24,6 +24,11 @@ struct ps_model {
   DevBuf<long long> rowcnt, rowoff, doff, tcnt, toff;
   DevBuf<int> pair_t, pair_tile;
   DevBuf<double> hm;
+  DevBuf<long long> np_dev;          // pair count of the batch in flight
+  long long* np_host = nullptr;      // pinned copy
+  long long last_np = 0;             // pair count of the previous batch (sizes the next one's lists without a host sync)
+  long long guessed_cap = -1;        // capacity the batch in flight was enqueued with (-1: exact, host-read offsets)
+  long long guess_key = -1, max_np = 0;   // batch shape (days, grid) the counts belong to; largest count seen for it
   DevBuf<int> rowrad;
   DevBuf<PeriodInfo> pinfo;
   DevBuf<DayInfo> dinfo;
@@ -112,6 +117,8 @@ extern "C" int ps_model_destroy(ps_model* m) {
   m->hprob.release(); m->scratch.release(); m->pmf.release(); m->psum.release(); m->pmin.release();
   m->rowsum.release(); m->rowcnt.release(); m->rowoff.release(); m->doff.release(); m->rowrad.release();
   m->tcnt.release(); m->toff.release(); m->pair_t.release(); m->pair_tile.release(); m->hm.release();
+  m->np_dev.release();
+  if (m->np_host) { (void)hipHostFree(m->np_host); m->np_host = nullptr; }
   m->pinfo.release(); m->dinfo.release(); m->orow.release(); m->ocol.release(); m->oval.release();
   m->stamp.release(); m->stampH.release();
   delete m;
@@ -137,10 +144,23 @@ extern "C" int ps_model_set_wind(ps_model* m, const double* wind, const int32_t*
   return PS_OK;
 }
 
+static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const double* start_time,
+                          const double* hparams, const double* Dparams, const double* Dlparams,
+                          double mu_r, int n_periods, double rad_dist, int rad_res,
+                          int32_t* kshape, int64_t* nnz, int32_t* warned, int32_t* status, bool allow_guess);
+
 extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, const double* start_time,
                                   const double* hparams, const double* Dparams, const double* Dlparams,
                                   double mu_r, int n_periods, double rad_dist, int rad_res,
                                   int32_t* kshape, int64_t* nnz, int32_t* warned, int32_t* status) {
+  return prob_mass_impl(m, nd, day_idx, start_time, hparams, Dparams, Dlparams, mu_r, n_periods, rad_dist, rad_res,
+                        kshape, nnz, warned, status, true);
+}
+
+static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const double* start_time,
+                          const double* hparams, const double* Dparams, const double* Dlparams,
+                          double mu_r, int n_periods, double rad_dist, int rad_res,
+                          int32_t* kshape, int64_t* nnz, int32_t* warned, int32_t* status, bool allow_guess) {
   if (!m || nd < 1 || !day_idx || !start_time || !hparams || !Dparams || !Dlparams)
     return ps_fail(PS_ERR_BAD_ARG, "prob_mass: bad arguments");
   if (m->ndw == 0) return ps_fail(PS_ERR_STATE, "prob_mass before set_wind");
@@ -182,7 +202,7 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
   hipStream_t st = m->stream;
   PS_HIP(hipMemcpyAsync(m->day_idx.p, day_idx, nd * sizeof(int), hipMemcpyHostToDevice, st));
   PS_HIP(hipMemcpyAsync(m->start_time.p, start_time, nd * sizeof(double), hipMemcpyHostToDevice, st));
-  PS_HIP(hipStreamSynchronize(st));
+  // (no synchronisation: copies from pageable host memory are staged before hipMemcpyAsync returns)
   hipLaunchKernelGGL(k_hprob, dim3(nd), dim3(256), (size_t)3 * T * sizeof(double), st, m->wind.p, mp, m->day_idx.p,
                      m->hprob.p, m->scratch.p);
   PS_HIP(hipGetLastError());
@@ -205,6 +225,46 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
     PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, m->tcnt.p, (int)ntot, m->toff.p);
     PS_HIP(hipGetLastError());
+    static const int seg = getenv("PS_PM_SEG") ? std::max(1, atoi(getenv("PS_PM_SEG"))) : 8;   // periods per record
+    const long long max_pairs = (long long)1 << 20;   // 2 GB of records per chunk
+    // The pair lists' length is known on the device only.  A batch like the previous one (sampler
+    // chains, ensemble members: same days, nearby parameters) sizes its lists from that one's count
+    // plus a quarter and enqueues everything without waiting for the scan; the real count comes back
+    // with the batch's statistics, and a batch that did not fit is redone the slow way (host reads the
+    // day offsets, chunks of at most 2 GB of records).  PS_PM_SYNC=1: always the slow way.
+    // (capacity: the previous batch's count plus a quarter, and never less than the largest count a
+    // batch of this shape has had -- an ensemble's members differ a lot, the first large one is redone
+    // once and sets the size for the rest)
+    const long long key = (long long)nd * 1000003LL + N;
+    if (key != m->guess_key) { m->guess_key = key; m->max_np = 0; m->last_np = 0; }
+    const long long cap = std::max(m->last_np + m->last_np / 4, m->max_np) + 4096;
+    bool guessed = false;
+    if (allow_guess && m->last_np > 0 && cap <= max_pairs && getenv("PS_PM_SYNC") == nullptr) {
+      guessed = true;
+      PS_TRY(m->np_dev.ensure(1));
+      if (!m->np_host) PS_HIP(hipHostMalloc((void**)&m->np_host, sizeof(long long), hipHostMallocDefault));
+      PS_TRY(m->pair_t.ensure((size_t)cap));
+      PS_TRY(m->pair_tile.ensure((size_t)cap));
+      PS_TRY(m->hm.ensure((size_t)cap * PM_CELLS));
+      hipLaunchKernelGGL(k_pair_total, dim3(1), dim3(64), 0, st, m->toff.p, m->tcnt.p, (long long)ntot, m->np_dev.p);
+      PS_HIP(hipGetLastError());
+      PS_HIP(hipMemcpyAsync(m->np_host, m->np_dev.p, sizeof(long long), hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(k_tile_fill, dim3(nt, nt, nd), dim3(256), 0, st, mp, m->pinfo.p, m->dinfo.p, m->tcnt.p,
+                         m->toff.p, 0, 0LL, cap, m->pair_t.p, m->pair_tile.p);
+      PS_HIP(hipGetLastError());
+      const long long nseg = (cap + seg - 1) / seg;
+      if (mp.rule.high)
+        hipLaunchKernelGGL(k_pair_masses<true>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, 0, nt, cap, seg,
+                           m->np_dev.p, m->pair_t.p, m->pair_tile.p, m->hm.p);
+      else
+        hipLaunchKernelGGL(k_pair_masses<false>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, 0, nt, cap, seg,
+                           m->np_dev.p, m->pair_t.p, m->pair_tile.p, m->hm.p);
+      PS_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_tile_accumulate, dim3(nt, nt, nd), dim3(PM_CELLS), 0, st, mp, m->tcnt.p, m->toff.p, 0,
+                         0LL, seg, cap, m->hm.p, m->pmf.p);
+      PS_HIP(hipGetLastError());
+    }
+    if (!guessed) {
     std::vector<long long> dayoff((size_t)nd + 1, 0);
     long long last_cnt = 0;
     // the first offset of every day in one strided copy
@@ -214,7 +274,8 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
     PS_HIP(hipMemcpyAsync(&last_cnt, m->tcnt.p + (ntot - 1), sizeof(long long), hipMemcpyDeviceToHost, st));
     PS_HIP(hipStreamSynchronize(st));
     dayoff[(size_t)nd] += last_cnt;
-    const long long max_pairs = (long long)1 << 20;   // 2 GB of records
+    m->last_np = dayoff[(size_t)nd];
+    m->max_np = std::max(m->max_np, m->last_np);
     int d0 = 0;
     while (d0 < nd) {
       int d1 = d0 + 1;
@@ -225,24 +286,25 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
         PS_TRY(m->pair_tile.ensure((size_t)np));
         PS_TRY(m->hm.ensure((size_t)np * PM_CELLS));
         hipLaunchKernelGGL(k_tile_fill, dim3(nt, nt, d1 - d0), dim3(256), 0, st, mp, m->pinfo.p, m->dinfo.p, m->tcnt.p,
-                           m->toff.p, d0, base, m->pair_t.p, m->pair_tile.p);
+                           m->toff.p, d0, base, np, m->pair_t.p, m->pair_tile.p);
         PS_HIP(hipGetLastError());
         // periods per record (PS_PM_SEG; 1 = one record per (tile, period) pair: sequential-loop sums)
-        static const int seg = getenv("PS_PM_SEG") ? std::max(1, atoi(getenv("PS_PM_SEG"))) : 8;
         const long long nseg = (np + seg - 1) / seg;
         if (mp.rule.high)
           hipLaunchKernelGGL(k_pair_masses<true>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg,
-                             m->pair_t.p, m->pair_tile.p, m->hm.p);
+                             (const long long*)nullptr, m->pair_t.p, m->pair_tile.p, m->hm.p);
         else
           hipLaunchKernelGGL(k_pair_masses<false>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg,
-                             m->pair_t.p, m->pair_tile.p, m->hm.p);
+                             (const long long*)nullptr, m->pair_t.p, m->pair_tile.p, m->hm.p);
         PS_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_tile_accumulate, dim3(nt, nt, d1 - d0), dim3(PM_CELLS), 0, st, mp, m->tcnt.p, m->toff.p, d0,
-                           base, seg, m->hm.p, m->pmf.p);
+                           base, seg, np, m->hm.p, m->pmf.p);
         PS_HIP(hipGetLastError());
       }
       d0 = d1;
     }
+    }   // !guessed
+    m->guessed_cap = guessed ? cap : -1;
   }
   hipLaunchKernelGGL(k_pmf_reduce1, dim3(nblk, nd), dim3(256), 0, st, m->pmf.p, n2, m->psum.p, m->pmin.p);
   PS_HIP(hipGetLastError());
@@ -260,6 +322,14 @@ extern "C" int ps_model_prob_mass(ps_model* m, int nd, const int32_t* day_idx, c
   m->hinfo.resize(nd);
   PS_HIP(hipMemcpyAsync(m->hinfo.data(), m->dinfo.p, nd * sizeof(DayInfo), hipMemcpyDeviceToHost, st));
   PS_HIP(hipStreamSynchronize(st));
+  if (m->guessed_cap >= 0) {
+    const long long np_real = *m->np_host;
+    m->last_np = np_real;
+    m->max_np = std::max(m->max_np, np_real);
+    if (np_real > m->guessed_cap)      // the lists were too short: everything behind them is void
+      return prob_mass_impl(m, nd, day_idx, start_time, hparams, Dparams, Dlparams, mu_r, n_periods, rad_dist, rad_res,
+                            kshape, nnz, warned, status, false);
+  }
   m->off.assign(nd + 1, 0);
   m->kshape.assign(nd, 0);
   for (int d = 0; d < nd; ++d) {
