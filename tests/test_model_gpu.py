@@ -223,3 +223,35 @@ def test_prob_mass_large_grids_against_reference(PM, golden, kalbar, carnarvon):
         _check_digest(g, 'car1024_member0',
                       PM.prob_mass(dc[3], wc, (lam,) + tuple(HP[1:]), (sx, sy, 0.253), DLP, mu, NPER, 10000.0, 1024))
         _check_digest(g, 'car2048_late', PM.prob_mass(dc[0], wc, HP, DP, DLP, MU_R, NPER, 10000.0, 2048, 0.93))
+
+
+def test_prob_mass_pair_list_overflow_is_redone(PM, kalbar, monkeypatch):
+    '''The pair stage of a batch is enqueued with list capacities guessed from the previous batches of
+    the same shape (no host sync behind the scan).  A batch with far more (tile, period) pairs than
+    any before it does not fit: it must be detected and redone with exact sizes -- bit-identical to
+    the always-exact path (PS_PM_SYNC=1) -- and so must the batches after it.'''
+    wd, days = kalbar
+    narrow = (DP[0] * 0.3, DP[1] * 0.3, DP[2])
+    wide = (DP[0] * 2.0, DP[1] * 2.0, DP[2])
+    seq = [narrow, narrow, wide, narrow, wide]
+
+    def run():
+        m = PM.WindModel(wd)
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            for dp in seq:
+                m.build(days[:3], HP, dp, DLP, MU_R, NPER, 10000.0, 128)
+                out.append([m.fetch(i) for i in range(3)])
+        m.close()
+        return out
+
+    monkeypatch.delenv('PS_PM_SYNC', raising=False)
+    got = run()
+    monkeypatch.setenv('PS_PM_SYNC', '1')
+    ref = run()
+    assert sum(r.nnz for r in ref[2]) > 2 * sum(r.nnz for r in ref[0])     # the wide batch really is much bigger
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and x.nnz == y.nnz
+            assert np.array_equal(x.row, y.row) and np.array_equal(x.col, y.col) and np.array_equal(x.data, y.data)
