@@ -54,6 +54,12 @@ struct ColFullArgs {
   double* pad_energy;
   int pad_row0, ncols_total;
   int col0;              // first column of this launch (blocks map to columns col0, col0 + 1, ...)
+  // k_colfull_day (mode 0): when *alt_pred is above the flag threshold -- the previous day raised the
+  // boundary flag (CalcSol.py:200-201) -- the state column is not state[c] but the forward transform of
+  // column c of alt_src, the row-pass output of that day's truncated field (rows as alt_live says)
+  const cplx* alt_src;
+  const unsigned long long* alt_pred;
+  RowLive alt_live;
   FftProg prog;          // the length-L row plan (its two-level twiddle table)
 };
 
@@ -79,7 +85,9 @@ static __global__ void k_pad_quiet(const double* energy, int ncols, double P, do
 // compiler turns into 162 registers and no scratch (255 us per day at L = 5184).  The templated
 // kernel below serves the other modes (114-128 registers) and the chained groups of days; its
 // one-day instance costs 246-256 registers and is 15-45 % slower than this one.
-template <int R1, int R2, int R3, bool CEX>
+// ALT: the instance that can take the state column from alt_src (see ColFullArgs); launched only
+// when a re-transform is pending, so the plain instance keeps its 162 registers
+template <int R1, int R2, int R3, bool CEX, bool ALT>
 __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullArgs a) {
   using S = Rs<R1, R2, R3>;
   constexpr int L = S::L;
@@ -100,6 +108,30 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
   cplx x[S::RMAX];
   cplx* st = a.state + (int64_t)blockIdx.y * a.state_bstride + (int64_t)c * L;
   if (a.mode != 2) {
+    // the re-transform of a flagged day's field, column half: done here instead of a pass of its own
+    // (one spectrum less read, one less written per flagged day); the values stay in registers
+    // while the kernel column is transformed
+    const bool alt = ALT && a.alt_pred && !pred_skip(a.alt_pred);
+    cplx sv[R3];
+    if (ALT && alt) {
+      const cplx* ac = a.alt_src + (int64_t)c * L;
+      if (j < S::T1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+          const int n = j + q * S::T1;
+          x[q] = make_double2(0.0, 0.0);
+          if (row_live(a.alt_live, n, 0)) x[q] = ac[n];
+        }
+        bfly<R1, PS_FWD>(x);
+      }
+      if constexpr (CEX) rs_tail_c<S, R1, R2, R3, PS_FWD>(x, exc, j, w2, w3);
+      else rs_tail<S, R1, R2, R3, PS_FWD>(x, ex, j, w2, w3);
+      if (j < S::T3) {
+#pragma unroll
+        for (int q = 0; q < R3; ++q) sv[q] = x[q];
+      }
+      __syncthreads();   // the exchange buffer goes to the kernel column's transform
+    }
     const cplx* sc = a.src + (int64_t)blockIdx.y * a.src_bstride + (int64_t)c * L;
     if (j < S::T1) {
 #pragma unroll
@@ -120,9 +152,10 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
       return;
     }
     if (j < S::T3) {
-      cplx sv[R3];
+      if (!alt) {
 #pragma unroll
-      for (int q = 0; q < R3; ++q) sv[q] = st[j + q * S::T3];
+        for (int q = 0; q < R3; ++q) sv[q] = st[j + q * S::T3];
+      }
 #pragma unroll
       for (int q = 0; q < R3; ++q) {
         x[q] = cmul(sv[q], x[q]);

@@ -268,6 +268,12 @@ struct ps_solver {
   DevBuf<double> pad_energy;
   DevBuf<int> pad_quiet;
   DevBuf<cplx> tail_hat;       // [day][column][Pf]: kernel spectra / chained products of the columns taken out of a chained pass
+  // Deferred column half of a flagged day's re-transform (full-column pipeline, one day per pass): the
+  // row pass of the truncated field has written Trow if *refft_pending fired, and then the state's
+  // spectrum is FFT_columns(Trow), not Ahat -- the next day pass transforms the column itself
+  // (k_colfull_day, alt_src), anything else goes through resolve_refft first
+  DevBuf<cplx> Trow;
+  const unsigned long long* refft_pending = nullptr;
   int ncu = 0;                 // compute units of the device
   // optional per-kernel-class HIP event timing (bench.py roofline leg)
   bool prof_on = false;
@@ -511,6 +517,8 @@ static bool colfull_dual(const ps_solver* s, int nd) {
   return dual_min > 0 && nd >= dual_min && rs_dual_ok(s->rs_r2, s->rs_r3);
 }
 
+static SrcMap map_plain(int n, int P);
+
 // col0 / ncols: the launch covers columns [col0, ncols) (default: all H); state_bstride / dst_bstride
 // override the per-batch-entry strides (default: one spectrum)
 static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, int store_prod, cplx* dst, int batch,
@@ -518,6 +526,13 @@ static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, 
                           int col0 = 0, int ncols = -1, int64_t state_bstride = -1, bool timed = true) {
   ColFullArgs a;
   a.pad_energy = nullptr;
+  a.alt_src = nullptr; a.alt_pred = nullptr; a.alt_live = RowLive{0, {0, 0, 0, 0}, nullptr};
+  if (s->refft_pending) {
+    if (!(mode == 0 && nd == 1 && batch == 1 && !pred && state == s->Ahat.p))
+      return ps_fail(PS_ERR_STATE, "full-column pass: a flagged day's re-transform is still pending");
+    a.alt_src = s->Trow.p; a.alt_pred = s->refft_pending;
+    a.alt_live = RowLive{1, map_plain(s->N, s->Pf), nullptr};
+  }
   a.pad_row0 = 2 * ((s->N + 1) / 2);   // first row of the first pad-only row pair
   a.ncols_total = s->H;
   a.col0 = col0;
@@ -920,6 +935,22 @@ static int finalize_days(ps_solver* s, int slot, int count, int renorm) {
 static int refft_if_flag(ps_solver* s, const double* rec, cplx* hat, int slot) {
   return fwd2d(s, rec, 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf), hat, 1,
                s->padmax.p + slot);
+}
+
+// ... the row half only, into Trow; the next day pass (or resolve_refft) does the columns
+static int refft_rows_if_flag(ps_solver* s, const double* rec, int slot) {
+  PS_TRY(s->Trow.ensure((size_t)s->Pf * s->ld));
+  const SrcMap m = map_plain(s->N, s->Pf);
+  PS_TRY(launch_row_fwd(s, rec, 0, s->N, m, m, s->Trow.p, 1, s->padmax.p + slot, 1, nullptr));
+  s->refft_pending = s->padmax.p + slot;
+  return PS_OK;
+}
+// the pending column half as a pass of its own: the state's spectrum is in Ahat afterwards
+static int resolve_refft(ps_solver* s) {
+  if (!s->refft_pending) return PS_OK;
+  const unsigned long long* pred = s->refft_pending;
+  s->refft_pending = nullptr;
+  return launch_colfull(s, 1, s->Trow.p, s->Ahat.p, 0, nullptr, 1, RowLive{1, map_plain(s->N, s->Pf), nullptr}, pred);
 }
 
 // fast-mode FFT size for a reference pad P: the smallest even 7-smooth size, or a size served
@@ -1635,6 +1666,11 @@ extern "C" int ps_chain_run(ps_solver* s, int first, int count, double negval, d
     s->kt_from = -1;
   }
   if (s) s->kt_lazy_from = -1;   // kernels this run never reached stay untransformed
+  // the last day's re-transform, if it was deferred: every other entry point finds the spectrum in Ahat
+  if (s && s->refft_pending) {
+    if (rc == PS_OK) return resolve_refft(s);
+    s->refft_pending = nullptr;
+  }
   return rc;
 }
 
@@ -1842,7 +1878,13 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
       double* rec = s->recs[PS_REC_CHAIN][d];
       PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, d, negval, stat_scale, s->krange.p + 2 * d));
-      if (with_refft) PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
+      if (with_refft) {
+        // full-column pipeline: only the row half now, the column half inside the next day's pass
+        // (PS_NO_DEFER_REFFT=1: A/B knob)
+        static const bool defer = getenv("PS_NO_DEFER_REFFT") == nullptr && getenv("PS_TPIPE_SPLIT") == nullptr;
+        if (s->tpipe && defer && rs_colfull_alt_ok(s->rs_r2, s->rs_r3)) PS_TRY(refft_rows_if_flag(s, rec, d));
+        else PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
+      }
       return PS_OK;
     };
     // Speculation on the boundary flag (CalcSol.py:200-201): windows of days are enqueued

@@ -24,4 +24,8 @@ struct RsCfg {
   // to the non-speculative chain: test_flag_speculation_is_exact_in_the_full_column_pipeline.)
   static constexpr bool CEX = 2 * LDSC1 <= (size_t)160 * 1024;
   static constexpr size_t LDSD = CEX ? 2 * LDSC1 : LDSC1;
+  // single-day pass that transforms a flagged day's truncated column itself (k_colfull_day ALT): R3
+  // more complex values stay in registers across the kernel column's transform -- the sizes where
+  // that still compiles without scratch
+  static constexpr bool ALT = S::NTHR <= 512 && R2 * R3 <= 450 && !(R2 == 21 && R3 == 21);
 };
