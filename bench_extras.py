@@ -77,7 +77,7 @@ def real_wind_case(rad_dist, R=2048, nd=30, mode='fast', device=None, reps=3, pr
            'P_reference': int(2 * R + 1 + int(ks.max()) // 2),
            'kshape_min': int(ks.min()), 'kshape_max': int(ks.max()),
            'grid_days_per_s': round((nd - 1) / dt, 2), 'chain_ms': round(dt * 1e3, 3),
-           'flagged_days': int(sum(flags)), 'days': nd - 1,
+           'flagged_days': int(sum(flags)), 'days': nd - 1, 'flag_pattern': ''.join('1' if f else '0' for f in flags),
            'kernels_direct': bool(s.kernels_direct),
            'auto_first_fold_day': s.auto_info()[0] if s.mode == 'auto' else None,
            'auto_fold_fft': s.auto_info()[1] if s.mode == 'auto' else None,

@@ -196,6 +196,11 @@ struct ps_solver {
   int kt_lazy_from = -1, kt_lazy_c0 = 0, kt_lazy_cn = 0;
   unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
   int hflags_n = 0;
+  // ... and of the previous chain run's, copied behind it and read when the next run starts: a solver that
+  // has seen a flag (speculate off) still chains the stretches of days that raised none last time
+  unsigned long long* hhist = nullptr;
+  int hhist_n = 0, hist_first = -1, hist_count = 0;
+  hipEvent_t hist_ev = nullptr;
   int rs_r2 = 0, rs_r3 = 0;   // register-resident row kernels (fft_rs.h) for Pf = 16 * rs_r2 * rs_r3, or 0
   int L1 = 0, L2 = 0;
   DevBuf<cplx> tp_lo, tp_hi;
@@ -1134,6 +1139,8 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   for (auto e : s->prof_pool) (void)hipEventDestroy(e);
   for (auto e : s->spec_ev) if (e) (void)hipEventDestroy(e);
   if (s->hflags) (void)hipHostFree(s->hflags);
+  if (s->hhist) (void)hipHostFree(s->hhist);
+  if (s->hist_ev) (void)hipEventDestroy(s->hist_ev);
   s->dkoff.release(); s->dkshape.release();
   s->torus.release(); s->lin.release(); s->fold_rowsum.release(); s->fold_rowcnt.release(); s->fold_padmax.release();
   delete s;
@@ -1684,7 +1691,9 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
   if (!s->kernels_on_device || first < 0 || count < 0 || first + count > s->nk)
     return ps_fail(PS_ERR_STATE, "chain_run: days [%d,%d) not uploaded (nk=%d)", first, first + count, s->nk);
   PS_HIP(hipSetDevice(s->device));
-  PS_TRY(ensure_stats(s, std::max(4, first + count)));
+  // sized for every uploaded day at once: a run continued in a second call must not lose the statistics
+  // of the first (growing the buffers does not keep their contents)
+  PS_TRY(ensure_stats(s, std::max(4, s->nk)));
   for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
   PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
   s->last_renorm = renorm;
@@ -1789,7 +1798,20 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
                            s->auto_first_regime == 1 ? 1.0 : 0.0);   // start where the last run's hand-over started
     if (s->auto_hint > 0) hint_abs = first + s->auto_hint;
   }
-  if (s->speculate) {
+  // flags of the previous run over the same days (see `guided` below)
+  std::vector<char> hist;
+  if (!s->auto_exact && !s->speculate && s->hist_count == count && s->hist_first == first && count >= 2 &&
+      getenv("PS_NO_FLAG_HISTORY") == nullptr && getenv("PS_NO_SPECULATION") == nullptr) {
+    PS_HIP(hipEventSynchronize(s->hist_ev));
+    hist.resize(count);
+    for (int i = 0; i < count; ++i) {
+      double m;
+      __builtin_memcpy(&m, &s->hhist[i], sizeof(double));
+      hist[i] = !(m <= 1e-8);   // NaN counts as flagged: no speculation on it
+    }
+  }
+  s->hist_count = 0;
+  if (s->speculate || !hist.empty()) {
     for (int i = 0; i < 2; ++i)
       if (!s->spec_ev[i]) PS_HIP(hipEventCreateWithFlags(&s->spec_ev[i], hipEventDisableTiming));
     if (s->hflags_n < first + count) {
@@ -1830,6 +1852,14 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     s->spec_window = w0;
     hinted = true;
   }
+  // A solver that has seen a flag no longer speculates blindly, but sampler chains and repeated runs raise
+  // their flags on much the same days every time: with the previous run's flags at hand, the stretches of
+  // >= 2 days that raised none go through the chained pass again (verified like any speculation window:
+  // a flag inside one sends the rest of the run down the safe path), every other day runs with its
+  // predicated re-transform, which is right whatever its flag says.  PS_NO_FLAG_HISTORY=1: A/B knob.
+  bool guided = false;
+  if (!hist.empty() && s->tpipe && colfull_chains(s))
+    for (int i = 0; i + 1 < count && !guided; ++i) guided = !hist[i] && !hist[i + 1];
   for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
     const int cn = std::min(s->chunk_days, first + count - c0);
     // Full-column pipeline, long chunk: only the kernels of the first three windows (2 + 4 + 8 days)
@@ -1881,7 +1911,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       if (with_refft) {
         // full-column pipeline: only the row half now, the column half inside the next day's pass
         // (PS_NO_DEFER_REFFT=1: A/B knob)
-        static const bool defer = getenv("PS_NO_DEFER_REFFT") == nullptr && getenv("PS_TPIPE_SPLIT") == nullptr;
+        const bool defer = getenv("PS_NO_DEFER_REFFT") == nullptr && getenv("PS_TPIPE_SPLIT") == nullptr;   // per day: tests flip it
         if (s->tpipe && defer && rs_colfull_alt_ok(s->rs_r2, s->rs_r3)) PS_TRY(refft_rows_if_flag(s, rec, d));
         else PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
       }
@@ -1901,7 +1931,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     (void)flagged_at;
     int d = c0, nev = 0;
     while (true) {
-      if (!s->speculate) {
+      if (!s->speculate && !guided) {
         for (; d < c0 + cn; ++d) PS_TRY(day(d, true));
         break;
       }
@@ -1911,6 +1941,17 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       while (q.size() < depth && d < c0 + cn && !(hint_abs >= 0 && d == hint_abs + 1 && !q.empty())) {
         int w = std::min(s->spec_window, c0 + cn - d);
         if (hint_abs >= d) w = std::min(w, hint_abs - d + 1);
+        if (guided) {
+          int g = 0;   // days from d on that raised no flag last time
+          while (d + g < c0 + cn && g < PS_MAX_GROUP_DAYS && !hist[d + g - first]) ++g;
+          if (g < 2) {   // nothing to verify behind a day that carries its own re-transform
+            PS_TRY(day(d, true));
+            ++d;
+            continue;
+          }
+          w = g;
+          PS_TRY(resolve_refft(s));   // the chained pass reads the state's spectrum
+        }
         // inside a window no flag is expected: days go through the fused pass in groups
         for (int i = 0; i < w;) {
           int g = 0;
@@ -1963,6 +2004,8 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
         __builtin_memcpy(&mf, &s->hflags[f], sizeof(double));
         return auto_handover(s, first, f, first + count, negval, stat_scale, renorm, mf);
       }
+      s->refft_pending = nullptr;   // belongs to a day behind f
+      guided = false;
       PS_TRY(fwd2d(s, s->recs[PS_REC_CHAIN][f], 0, s->N, map_plain(s->N, s->Pf), map_plain(s->N, s->Pf),
                    s->Ahat.p, 1, nullptr));
       if (d - f - 1 > 0)
@@ -1972,6 +2015,21 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     }
   }
   if (s->speculate && flagged_at < 0) s->noflag_hint = count;
+  if (!s->auto_exact && !s->speculate && count >= 2 && getenv("PS_NO_FLAG_HISTORY") == nullptr) {
+    if (s->hhist_n < count) {
+      if (s->hist_ev) PS_HIP(hipEventSynchronize(s->hist_ev));   // an earlier run's copy may still be on its way
+      if (s->hhist) (void)hipHostFree(s->hhist);
+      s->hhist = nullptr;
+      s->hhist_n = 0;
+      PS_HIP(hipHostMalloc((void**)&s->hhist, (size_t)(count + 32) * sizeof(unsigned long long), hipHostMallocDefault));
+      s->hhist_n = count + 32;
+    }
+    if (!s->hist_ev) PS_HIP(hipEventCreateWithFlags(&s->hist_ev, hipEventDisableTiming));
+    PS_HIP(hipMemcpyAsync(s->hhist, s->padmax.p + first, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    PS_HIP(hipEventRecord(s->hist_ev, s->stream));
+    s->hist_first = first;
+    s->hist_count = count;
+  }
   return PS_OK;
 }
 

@@ -377,6 +377,48 @@ def test_flag_speculation_is_exact_in_the_full_column_pipeline(hip_lib, monkeypa
             assert bool(flags[d]) == bool(trace['flags'][d])
 
 
+def test_deferred_column_retransform_is_bit_identical(hip_lib, monkeypatch):
+    """After a flagged day the full-column pipeline transforms only the ROWS of the truncated field;
+    the column half runs inside the next day's pass (k_colfull_day ALT), the last day's as a pass of
+    its own when the run ends.  Same bits as the separate re-transform (PS_NO_DEFER_REFFT=1), half
+    the predicated launches, and a run split in two (the pending column half is resolved between
+    them) continues to the same fields."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    monkeypatch.setenv('PS_NO_SPECULATION', '1')
+    R, K, nd = 400, 401, 12
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+    state = sparse.coo_matrix(([1.0], ([785], [785])), shape=(N, N))
+    runs = {}
+    for tag in ('deferred', 'separate', 'split'):
+        if tag == 'separate':
+            monkeypatch.setenv('PS_NO_DEFER_REFFT', '1')
+        else:
+            monkeypatch.delenv('PS_NO_DEFER_REFFT', raising=False)
+        s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+        assert s.fft_len == 1008
+        s.set_kernels(kernels)
+        s.prof_enable(True, every=1)
+        if tag == 'split':
+            s.run_chain(0, 5, renorm=True)
+            s.run_chain(5, nd - 5, renorm=True)
+        else:
+            s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        prof = s.prof_read()
+        assert s.full_column
+        runs[tag] = ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st],
+                     prof['refft_pred'][1])
+        s.close()
+    assert sum(f for f, _, _, _ in runs['separate'][1]) >= 3          # flags did fire
+    assert runs['separate'][2] == 2 * nd and runs['deferred'][2] == nd + 1 and runs['split'][2] == nd + 2
+    for tag in ('deferred', 'split'):
+        assert runs[tag][1] == runs['separate'][1]
+        for a, b in zip(runs[tag][0], runs['separate'][0]):
+            assert np.array_equal(a, b)
+
+
 def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
     """PS_MODE_AUTO past the clean prefix: flagged and clean days on the wide fast torus
     (N + 2M), dusty days in the fold child, hand-overs in both directions -- forced on for small
@@ -528,6 +570,56 @@ def test_window_hint_changes_nothing(hip_lib, monkeypatch):
     assert c[1] == d[1]
     for x, y in zip(c[0], d[0]):
         assert np.array_equal(x, y)
+
+
+def test_flag_history_chains_the_quiet_stretches(hip_lib, monkeypatch):
+    """A solver that has seen a flag stops speculating blindly; from its second run over the same days on it
+    chains the stretches that raised no flag last time (verified like any speculation window) and gives
+    every other day its predicated re-transform.  Same bits as one safe day at a time
+    (PS_NO_FLAG_HISTORY=1) -- when the flags repeat, when the next state flags EARLIER than the history
+    says (a flag inside a chained stretch: the rest of the run is redone the safe way), and when it flags
+    later or not at all."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    R, K, nd = 400, 401, 16
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+    pt = lambda c: sparse.coo_matrix(([1.0], ([c], [c])), shape=(N, N))
+    late, early, never = pt(700), pt(730), pt(400)
+
+    def run(s, state):
+        s.set_state(state)
+        s.prof_enable(True, every=1)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        days = s.prof_days()
+        chained = sum(days[k] for k in ('col_inv_a_x2', 'col_inv_a_x4', 'col_inv_a_x8', 'col_inv_a_xn'))
+        return ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st], chained)
+
+    order = (late, late, late, early, early, never, never, late)
+    out = {}
+    for tag in ('history', 'plain'):
+        if tag == 'plain':
+            monkeypatch.setenv('PS_NO_FLAG_HISTORY', '1')
+        s = hip_lib.HipSolve(late, [K, K], mode='fast', chain_only=True)
+        assert s.fft_len == 1008 and s.full_column
+        s.set_kernels(kernels)
+        out[tag] = [run(s, st) for st in order]
+        s.close()
+    flags = [[f for f, _, _, _ in r[1]] for r in out['plain']]
+    first = [f.index(1) if 1 in f else nd for f in flags]
+    assert first[3] < first[0] < nd and first[0] >= 3 and first[5] == nd, first      # early < late < never
+    for i, (h, p) in enumerate(zip(out['history'], out['plain'])):
+        assert h[1] == p[1], i
+        for a, b in zip(h[0], p[0]):
+            assert np.array_equal(a, b), i
+    # run 0 speculates until its first flag; the plain solver never chains again, the other one chains the
+    # leading quiet stretch of runs 1, 2 (flags repeat), 3 (flags earlier: stretch redone), 5, 6, 7
+    assert all(r[2] == 0 for r in out['plain'][1:])
+    chained = [r[2] for r in out['history']]
+    assert chained[1] >= first[0] - 1 and chained[2] == chained[1], chained
+    assert chained[6] == nd, chained                                     # history "no flag at all": one window
+    assert chained[4] >= first[3] - 1, chained
 
 
 def test_second_stream_kernel_transforms_change_nothing(hip_lib, monkeypatch):
