@@ -276,23 +276,28 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
   int pend_b = 0, pend_ra = 0, par = 0;
   const bool finalizer = j0 == S::NTHR - 1;
 
-  int u = (int)blockIdx.x;
+  // Pad-only pairs of a day whose pad_quiet entry is set are not units of work at all: the column pass
+  // summed |x|^2 over ALL pad-only rows of that day and found even that total below what one pair needs
+  // to reach pad_floor, so every pair's own Parseval test (below) would skip it.  The round-robin walks
+  // past them -- a skipped unit in the loop would start the next pair's prefetch and then wait for it
+  // with nothing to do meanwhile, once per day and workgroup.
+  auto next_unit = [&](int v) {   // uniform
+    while (v < units && a.pad_quiet) {
+      const int vb = v / npairs, vp = v - vb * npairs;
+      if (2 * vp < a.N || !a.pad_quiet[vb]) break;
+      v += (int)gridDim.x;
+    }
+    return v;
+  };
+  int u = next_unit((int)blockIdx.x), nu = 0;
   if (u < units) prefetch(u);
   PS_WAIT_VM0();
-  for (; u < units; u += (int)gridDim.x) {
+  for (; u < units; u = nu) {
+    nu = next_unit(u + (int)gridDim.x);
     const int b = u / npairs, pair = u - b * npairs;
     const int ra = 2 * pair, rb = ra + 1;
     const bool hasb = rb < a.P;
     const bool pad_only = ra >= a.N;
-    if (pad_only && a.pad_quiet && a.pad_quiet[b]) {   // uniform per workgroup
-      // The column pass summed |x|^2 over ALL pad-only rows of this day and found even that total
-      // below what one pair needs to reach pad_floor: every pair's own Parseval test (below) would
-      // skip it.  Nothing was prefetched for it; only the next unit's prefetch has to be started.
-      // (no barrier: the staging area was released by the previous round's second barrier)
-      if (u + (int)gridDim.x < units) prefetch(u + (int)gridDim.x);
-      PS_WAIT_VM0();
-      continue;
-    }
     // opaque per-round copies: nothing derived from the thread index or the stage twiddles is
     // loop-invariant for the compiler, which would otherwise hoist ~100 registers of twiddle
     // powers and LDS addresses out of the loop (and spill)
@@ -320,7 +325,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
       if (lane == 63) ered[wave] = energy;
     }
     PS_BAR_LDS();                               // staging is free again
-    if (u + (int)gridDim.x < units) prefetch(u + (int)gridDim.x);
+    if (nu < units) prefetch(nu);
     if (pad_only) {
       // Parseval bound on the largest value of a pad-only pair (see k_row_inv)
       double e = 0.0;
