@@ -66,6 +66,11 @@ struct RowFwdArgs {
   const int* rowrange;  // device [batch][2] inclusive live source-row range, or nullptr
   int nblocks;          // work items along x (grid.x may be smaller: the kernel loops)
   const unsigned long long* pred;
+  // k_row_fwd_rs: when *trunc_pred is above the flag threshold the source counts as truncated to its
+  // first trunc_n rows and columns (PS_MODE_FOLD: the torus of a flagged day, CalcSol.py:200-201); rows
+  // that are live only without the truncation are written as zeros (the column pass still reads them)
+  const unsigned long long* trunc_pred;
+  int trunc_n;
   FftProg prog;
 };
 

@@ -443,8 +443,14 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
   cplx* dst = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
   const int rlo = a.rowrange ? a.rowrange[2 * blockIdx.y] : 0;
   const int rhi = a.rowrange ? a.rowrange[2 * blockIdx.y + 1] : 0x7fffffff;
+  SrcMap rmap = a.rmap, cmap = a.cmap;
+  const bool trunc = a.trunc_pred && !pred_skip(a.trunc_pred);
+  if (trunc) {
+    rmap.n1 = rmap.n1 < a.trunc_n ? rmap.n1 : a.trunc_n;
+    cmap.n1 = cmap.n1 < a.trunc_n ? cmap.n1 : a.trunc_n;
+  }
   auto srow = [&](int r) {
-    const int sr = r < a.P ? src_map(a.rmap, r) : -1;
+    const int sr = r < a.P ? src_map(rmap, r) : -1;
     return (sr < rlo || sr > rhi) ? -1 : sr;
   };
   const int sa = srow(ra), sb = srow(rb);
@@ -454,7 +460,8 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
   cplx* db = dst + (a.tstride ? (int64_t)rb : (int64_t)rb * a.ld);
   const bool hasb = rb < a.P;
   if (sa < 0 && sb < 0) {   // uniform per row pair
-    if (a.skip_zero) return;
+    const bool cut = trunc && ((ra < a.P && src_map(a.rmap, ra) >= 0) || (rb < a.P && src_map(a.rmap, rb) >= 0));
+    if (a.skip_zero && !cut) return;
     const cplx z = make_double2(0.0, 0.0);
     for (int k = j; k < a.H; k += S::NTHR) {
       da[k * kst] = z;
@@ -471,7 +478,7 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_fwd_rs(RowF
     const double* pb = src + (int64_t)(sb >= 0 ? sb : 0) * a.src_ld;
 #pragma unroll
     for (int q = 0; q < R1; ++q) {
-      const int sc = src_map(a.cmap, j + q * S::T1);
+      const int sc = src_map(cmap, j + q * S::T1);
       const bool ok = sc >= 0;
       const int c = ok ? sc : 0;
       const double va = pa[c], vb = pb[c];          // always in bounds; masked below

@@ -278,6 +278,7 @@ struct ps_solver {
   // spectrum is FFT_columns(Trow), not Ahat -- the next day pass transforms the column itself
   // (k_colfull_day, alt_src), anything else goes through resolve_refft first
   DevBuf<cplx> Trow;
+  DevBuf<unsigned long long> one_flag;   // a pad maximum that always counts as "fired" (PS_MODE_FOLD day passes)
   const unsigned long long* refft_pending = nullptr;
   int ncu = 0;                 // compute units of the device
   // optional per-kernel-class HIP event timing (bench.py roofline leg)
@@ -368,8 +369,11 @@ static int set_lds_attr() {
 
 static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, int src_ld,
                           SrcMap rmap, SrcMap cmap, cplx* dst, int batch,
-                          const unsigned long long* pred, int skip_zero = 0, const int* rowrange = nullptr) {
+                          const unsigned long long* pred, int skip_zero = 0, const int* rowrange = nullptr,
+                          const unsigned long long* trunc_pred = nullptr, int trunc_n = 0) {
   RowFwdArgs a;
+  if (trunc_pred && s->rs_r2 == 0) return ps_fail(PS_ERR_STATE, "row pass: only the register-resident kernels truncate on the fly");
+  a.trunc_pred = trunc_pred; a.trunc_n = trunc_n;
   a.src = src; a.src_bstride = src_bstride; a.src_ld = src_ld;
   a.rmap = rmap; a.cmap = cmap;
   a.dst = dst; a.dst_bstride = (int64_t)s->Pf * s->ld;
@@ -523,15 +527,23 @@ static bool colfull_dual(const ps_solver* s, int nd) {
 }
 
 static SrcMap map_plain(int n, int P);
+// state column of a single-day pass from a row-pass output instead of the stored spectrum (ColFullArgs::alt_src)
+struct ColAlt { const cplx* src; const unsigned long long* pred; RowLive live; };
 
 // col0 / ncols: the launch covers columns [col0, ncols) (default: all H); state_bstride / dst_bstride
 // override the per-batch-entry strides (default: one spectrum)
 static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, int store_prod, cplx* dst, int batch,
                           RowLive live, const unsigned long long* pred, int nd = 1, double* pad_energy = nullptr,
-                          int col0 = 0, int ncols = -1, int64_t state_bstride = -1, bool timed = true) {
+                          int col0 = 0, int ncols = -1, int64_t state_bstride = -1, bool timed = true,
+                          const ColAlt* alt = nullptr) {
   ColFullArgs a;
   a.pad_energy = nullptr;
   a.alt_src = nullptr; a.alt_pred = nullptr; a.alt_live = RowLive{0, {0, 0, 0, 0}, nullptr};
+  if (alt) {   // PS_MODE_FOLD: the state column always comes from the row pass of the torus
+    if (!(mode == 0 && nd == 1 && batch == 1 && !pred) || s->refft_pending)
+      return ps_fail(PS_ERR_STATE, "full-column pass: an alternative state source needs a plain single-day pass");
+    a.alt_src = alt->src; a.alt_pred = alt->pred; a.alt_live = alt->live;
+  }
   if (s->refft_pending) {
     if (!(mode == 0 && nd == 1 && batch == 1 && !pred && state == s->Ahat.p))
       return ps_fail(PS_ERR_STATE, "full-column pass: a flagged day's re-transform is still pending");
@@ -1128,6 +1140,8 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
   s->tp_lo.release(); s->tp_hi.release();
   s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release(); s->Fhat.release();
+  s->Trow.release(); s->one_flag.release(); s->tail_hat.release(); s->pad_energy.release(); s->pad_quiet.release();
+  s->srange.release();
   s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release(); s->krange.release();
   for (auto& v : s->recs)
     for (double* p : v)
@@ -1711,12 +1725,43 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     PS_TRY(s->fold_padmax.ensure(1));
     PS_TRY(ensure_temps(s, 1));
     PS_TRY(s->T2.ensure(spec));
+    // Full-column pipeline on a size whose day pass can transform the state column itself (ALT): the day is
+    // row pass of the torus -> day pass (state column + kernel column -> product -> inverse) -> row pass
+    // -> fold; the forward column pass of the state and the truncation of a flagged day's torus are no
+    // launches of their own (the next row pass reads the flag and leaves the pad region out; the torus
+    // itself is truncated once, when the run ends).  PS_NO_FOLD_FUSE=1: A/B knob.
+    const bool fuse = s->tpipe && s->rs_r2 != 0 && rs_colfull_alt_ok(s->rs_r2, s->rs_r3) && getenv("PS_NO_FOLD_FUSE") == nullptr;
+    if (fuse && !s->one_flag.p) {
+      PS_TRY(s->one_flag.ensure(1));
+      const double one = 1.0;
+      PS_HIP(hipMemcpyAsync(s->one_flag.p, &one, sizeof(double), hipMemcpyHostToDevice, s->stream));
+      PS_HIP(hipStreamSynchronize(s->stream));   // `one` is a stack variable
+    }
     for (int c0 = first; c0 < first + count; c0 += s->chunk_days) {
       const int cn = std::min(s->chunk_days, first + count - c0);
       PS_TRY(transform_kernels(s, c0, cn));
       for (int d = c0; d < c0 + cn; ++d) {
         const cplx* B = s->Bhat.p + (size_t)(d - s->bhat_first) * s->Pf * s->ld;
         const SrcMap tmap = map_plain(s->Pref, s->Pf);
+        if (fuse) {
+          PS_TRY(launch_row_fwd(s, s->torus.p, 0, s->Pref, tmap, tmap, s->T1.p, 1, nullptr, 1, nullptr,
+                                d > first ? s->padmax.p + d - 1 : nullptr, s->N));
+          RowLive klive = s->kt_live;
+          klive.range = s->krange.p + 2 * d;
+          const ColAlt alt{s->T1.p, s->one_flag.p, RowLive{1, tmap, nullptr}};
+          PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr, 1, nullptr, 0, -1, -1, true, &alt));
+          PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
+          hipLaunchKernelGGL(k_fold, dim3(s->Pref), dim3(256), 0, s->stream, s->lin.p, s->Pf, s->Pref, s->N, s->M,
+                             s->torus.p, s->recs[PS_REC_CHAIN][d], negval, stat_scale,
+                             s->rowsum.p + (int64_t)d * s->N, s->rowcnt.p + (int64_t)d * s->N, s->padmax.p + d);
+          PS_HIP(hipGetLastError());
+          if (d == first + count - 1) {   // the run ends here: what the next run (or a hand-over) finds is truncated for real
+            hipLaunchKernelGGL(k_truncate_if_flag, dim3(s->Pref), dim3(256), 0, s->stream, s->torus.p, s->Pref, s->N,
+                               s->padmax.p + d);
+            PS_HIP(hipGetLastError());
+          }
+          continue;
+        }
         if (s->tpipe) {
           // full-column pipeline: state row pass (column-major out) -> one forward column pass ->
           // day pass (kernel column x state column -> inverse; the product is not kept: the state
