@@ -572,6 +572,47 @@ def test_window_hint_changes_nothing(hip_lib, monkeypatch):
         assert np.array_equal(x, y)
 
 
+def test_fold_mode_fused_day_is_bit_identical(hip_lib, monkeypatch):
+    """PS_MODE_FOLD on the full-column pipeline: the forward column transform of the state runs inside the
+    day pass (k_colfull_day ALT on the row pass of the torus) and a flagged day's truncation inside the next
+    row pass (k_row_fwd_rs reads the flag; the torus itself is truncated when the run ends).  Same bits as
+    the separate launches (PS_NO_FOLD_FUSE=1), also for a run split in two, with flags on both sides of
+    the split."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    R, K, nd = 400, 401, 10
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+    state = sparse.coo_matrix(([1.0], ([730], [730])), shape=(N, N))
+    runs = {}
+    for tag in ('fused', 'separate', 'split'):
+        if tag == 'separate':
+            monkeypatch.setenv('PS_NO_FOLD_FUSE', '1')
+        else:
+            monkeypatch.delenv('PS_NO_FOLD_FUSE', raising=False)
+        s = hip_lib.HipSolve(state, [K, K], mode='fold', chain_only=True)
+        assert s.mode == 'fold' and s.full_column
+        s.set_kernels(kernels)
+        s.prof_enable(True, every=1)
+        if tag == 'split':
+            s.run_chain(0, 4, renorm=True)
+            s.run_chain(4, nd - 4, renorm=True)
+        else:
+            s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        prof = s.prof_read()
+        runs[tag] = ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st],
+                     prof['col_fwd_a'][1])
+        s.close()
+    flags = [f for f, _, _, _ in runs['separate'][1]]
+    assert sum(flags[:4]) >= 1 and sum(flags[4:]) >= 1 and not all(flags), flags
+    assert runs['separate'][2] == nd and runs['fused'][2] == 0 and runs['split'][2] == 0
+    for tag in ('fused', 'split'):
+        assert runs[tag][1] == runs['separate'][1]
+        for a, b in zip(runs[tag][0], runs['separate'][0]):
+            assert np.array_equal(a, b)
+
+
 def test_flag_history_chains_the_quiet_stretches(hip_lib, monkeypatch):
     """A solver that has seen a flag stops speculating blindly; from its second run over the same days on it
     chains the stretches that raised no flag last time (verified like any speculation window) and gives
