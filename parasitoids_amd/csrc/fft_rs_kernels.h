@@ -181,6 +181,164 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
 }
 
 
+// ------------------------------------------------------------ inverse rows + fold (PS_MODE_FOLD)
+// The inverse row pass of the full linear-convolution field (M x M, y in [-m, P + m) with negative y
+// at M + y) and its fold back onto the reference's P-torus (k_fold: c[x] = lin[x] + lin[x + P] for
+// x < m, + lin[x - P + M] for x >= P - m, per dimension) in one kernel: the field itself never goes to
+// HBM.  What makes that possible is the pairing of the rows: the two real rows that travel through one
+// complex transform are a torus row's own two sources (r, r + P) or (r, r - P + M) wherever it has two
+// -- after the transform their sum is Re + Im of the same register -- and two neighbours (r, r + 1)
+// in the middle of the torus where a row has one source.  The fold along the row needs values of other
+// threads: one trip through the exchange buffer per output row.  Needs P >= 2 m (a row folds at most
+// once).  Writes what k_fold writes: the P x P torus (next day's state), the raw N x N record, the row
+// statistics of r_small_vals (CalcSol.py:126-135) and the maximum over the pad region (CalcSol.py:36-37).
+// Sums are formed rows first, then columns (k_fold: one element after the other): equal to round-off.
+struct RowFoldArgs {
+  const cplx* src;   // column-pass output, row-major [M][ld]
+  int ld, M, P, N, m;
+  double scale, negval, stat_scale;
+  double* torus;     // [P][P]
+  double* rec;       // [N][N]
+  double* rowsum;
+  long long* rowcnt;
+  unsigned long long* padmax;
+  FftProg prog;
+};
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_fold(RowFoldArgs a) {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  constexpr int L = S::L;
+  constexpr int NW = S::NTHR / 64;
+  double* ex = reinterpret_cast<double*>(ps_lds_raw);
+  double* red = ex + Y::XW;
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  // unit -> rows (uniform): [0, m) rows with a partner above, [m, 2m) rows with a partner below (stored at
+  // the top of the M-torus), then the middle rows two by two
+  const int u = (int)blockIdx.x;
+  int ra, rb;
+  bool summed, hasb = true;
+  if (u < a.m) { ra = u; rb = u + a.P; summed = true; }
+  else if (u < 2 * a.m) { ra = a.P - a.m + (u - a.m); rb = ra - a.P + a.M; summed = true; }
+  else { ra = a.m + 2 * (u - 2 * a.m); rb = ra + 1; summed = false; hasb = rb < a.P - a.m; }
+  const cplx* pa = a.src + (int64_t)ra * a.ld;
+  const cplx* pb = a.src + (int64_t)(hasb ? rb : ra) * a.ld;
+  const FftProg& P = a.prog;
+  const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
+  const cplx w3 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j < S::T3 ? S::tw3(j) : 0);
+  cplx x[S::RMAX];
+  if (j < S::T1) {   // Z = A + i B, Hermitian-extended while loading (as k_row_inv_rs)
+    auto idx = [&](int q) -> unsigned {
+      const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);
+      const unsigned i = (unsigned)j + (unsigned)(q * S::T1);
+      return direct ? i : (unsigned)L - i;
+    };
+#pragma unroll
+    for (int q = 0; q < R1; ++q) x[q] = pa[idx(q)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cplx B[R1 / 2];
+#pragma unroll
+      for (int v = 0; v < R1 / 2; ++v) B[v] = pb[idx(h * (R1 / 2) + v)];
+#pragma unroll
+      for (int v = 0; v < R1 / 2; ++v) {
+        const int q = h * (R1 / 2) + v;
+        const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);
+        const cplx A = x[q];
+        if (!hasb) B[v] = make_double2(0.0, 0.0);
+        x[q] = direct ? make_double2(A.x - B[v].y, A.y + B[v].x)
+                      : make_double2(A.x + B[v].y, B[v].x - A.y);
+      }
+    }
+    bfly<R1, PS_INV>(x);
+  }
+  rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);   // thread j < T3: columns j + q T3 of rows ra (Re), rb (Im)
+
+  double pmax = 0.0;
+  // one output row: its values along the row through the exchange buffer, folded, written, counted
+  auto emit = [&](const double (&w)[R3], int r, double& sum, int& cnt) {
+    __syncthreads();   // the buffer is free (last transform stage / previous row read)
+    if (j < S::T3) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) ex[j + q * S::T3] = w[q];
+    }
+    __syncthreads();
+    if (j < S::T3) {
+      double* trow = a.torus + (int64_t)r * a.P;
+      double* rrow = a.rec + (int64_t)r * a.N;
+      const bool dom_r = r < a.N;
+#pragma unroll
+      for (int q = 0; q < R3; ++q) {
+        const int c = j + q * S::T3;
+        if (c < a.P) {
+          double t = w[q];
+          if (c < a.m) t += ex[c + a.P];
+          if (c >= a.P - a.m) t += ex[c - a.P + a.M];
+          trow[c] = t;
+          if (dom_r && c < a.N) {
+            rrow[c] = t;
+            const double tt = t * a.stat_scale;
+            if (!(tt < a.negval)) { sum += tt; ++cnt; }
+          } else {
+            pmax = fmax(pmax, t);
+          }
+        }
+      }
+    }
+  };
+  double sa = 0.0, sb = 0.0;
+  int ca = 0, cb = 0;
+  {
+    double w[R3];
+    if (summed) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) w[q] = x[q].x * a.scale + x[q].y * a.scale;
+      emit(w, ra, sa, ca);
+    } else {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) w[q] = x[q].x * a.scale;
+      emit(w, ra, sa, ca);
+      if (hasb) {   // uniform
+#pragma unroll
+        for (int q = 0; q < R3; ++q) w[q] = x[q].y * a.scale;
+        emit(w, rb, sb, cb);
+      }
+    }
+  }
+  // deterministic block reduction (fixed DPP tree, then waves in order)
+  sa = ps_wave_sum(sa);
+  sb = ps_wave_sum(sb);
+  ca = ps_wave_sum_i32(ca);
+  cb = ps_wave_sum_i32(cb);
+  pmax = ps_wave_max0(pmax);
+  double* redm = red + 4 * NW;
+  if (lane == 63) {
+    red[wave * 4 + 0] = sa;
+    red[wave * 4 + 1] = sb;
+    red[wave * 4 + 2] = (double)ca;
+    red[wave * 4 + 3] = (double)cb;
+    redm[wave] = pmax;
+  }
+  __syncthreads();
+  if (j == 0) {
+    double ta = 0, tb = 0, na = 0, nbb = 0, mx = 0;
+    for (int w = 0; w < NW; ++w) {
+      ta += red[w * 4 + 0];
+      tb += red[w * 4 + 1];
+      na += red[w * 4 + 2];
+      nbb += red[w * 4 + 3];
+      mx = fmax(mx, redm[w]);
+    }
+    if (ra < a.N) { a.rowsum[ra] = ta; a.rowcnt[ra] = (long long)na; }
+    if (!summed && hasb && rb < a.N) { a.rowsum[rb] = tb; a.rowcnt[rb] = (long long)nbb; }
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+    if (mx > 0.0 && bits > __hip_atomic_load(a.padmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(a.padmax, bits);
+  }
+}
+
+
 // ------------------------------------------------------------ inverse rows, persistent + prefetch
 // Same transform and epilogue as k_row_inv_rs, organised for ONE workgroup per CU that walks its
 // share of the row pairs.  What k_row_inv_rs cannot do with one resident workgroup -- fetch the

@@ -41,6 +41,10 @@ int rs_rows_set_attrs() {
       auto kp = k_row_inv_rsp<16, A, B>;                                                                     \
       if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z::bytes) != hipSuccess) return -1; \
     }                                                                                                        \
+    if (C::LDSC1 > 48 * 1024) {                                                                              \
+      auto kr = k_row_inv_fold<16, A, B>;                                                                    \
+      if (hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDSC1) != hipSuccess) return -1; \
+    }                                                                                                        \
     if (C::LDS > 48 * 1024) {                                                                                \
       auto ki = k_row_inv_rs<16, A, B, np>;                                                                  \
       auto kf = k_row_fwd_rs<16, A, B, np>;                                                                  \
@@ -69,6 +73,19 @@ int rs_launch_row_fwd(int r2, int r3, const RowFwdArgs& a, int npairs, int batch
     constexpr int np = C::NP;                                                                                \
     auto kern = k_row_fwd_rs<16, A, B, np>;                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid_x(npairs, np, a.tstride), batch), dim3(C::S::NTHR * np), C::LDS, st, a); \
+    return 1;                                                                                                \
+  }
+  PS_RS_SIZES(X)
+#undef X
+  return 0;
+}
+
+int rs_launch_row_fold(int r2, int r3, const RowFoldArgs& a, int units, hipStream_t st) {
+#define X(A, B)                                                                                              \
+  if (r2 == A && r3 == B) {                                                                                  \
+    using C = RsCfg<A, B>;                                                                                   \
+    auto kern = k_row_inv_fold<16, A, B>;                                                                    \
+    hipLaunchKernelGGL(kern, dim3(units), dim3(C::S::NTHR), C::LDSC1, st, a);                                \
     return 1;                                                                                                \
   }
   PS_RS_SIZES(X)

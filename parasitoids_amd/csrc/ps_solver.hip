@@ -1750,11 +1750,28 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
           klive.range = s->krange.p + 2 * d;
           const ColAlt alt{s->T1.p, s->one_flag.p, RowLive{1, tmap, nullptr}};
           PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr, 1, nullptr, 0, -1, -1, true, &alt));
-          PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
-          hipLaunchKernelGGL(k_fold, dim3(s->Pref), dim3(256), 0, s->stream, s->lin.p, s->Pf, s->Pref, s->N, s->M,
-                             s->torus.p, s->recs[PS_REC_CHAIN][d], negval, stat_scale,
-                             s->rowsum.p + (int64_t)d * s->N, s->rowcnt.p + (int64_t)d * s->N, s->padmax.p + d);
-          PS_HIP(hipGetLastError());
+          // inverse row pass and fold in one kernel (the M x M field never goes to HBM) when a torus row
+          // folds at most once; PS_NO_FOLD_ROWS=1: A/B knob
+          if (s->Pref >= 2 * s->M && getenv("PS_NO_FOLD_ROWS") == nullptr) {
+            RowFoldArgs fa;
+            fa.src = s->T2.p; fa.ld = s->ld; fa.M = s->Pf; fa.P = s->Pref; fa.N = s->N; fa.m = s->M;
+            fa.scale = 1.0 / ((double)s->Pf * (double)s->Pf); fa.negval = negval; fa.stat_scale = stat_scale;
+            fa.torus = s->torus.p; fa.rec = s->recs[PS_REC_CHAIN][d];
+            fa.rowsum = s->rowsum.p + (int64_t)d * s->N; fa.rowcnt = s->rowcnt.p + (int64_t)d * s->N;
+            fa.padmax = s->padmax.p + d;
+            fa.prog = s->row_plan.prog;
+            const int units = 2 * s->M + (s->Pref - 2 * s->M + 1) / 2;
+            ProfScope prof(s, PS_PROF_ROW_INV);
+            if (!rs_launch_row_fold(s->rs_r2, s->rs_r3, fa, units, s->stream))
+              return ps_fail(PS_ERR_STATE, "no fold row kernel for 16 x %d x %d", s->rs_r2, s->rs_r3);
+            PS_HIP(hipGetLastError());
+          } else {
+            PS_TRY(launch_row_inv(s, s->T2.p, s->lin.p, d, 1, negval, stat_scale, true));
+            hipLaunchKernelGGL(k_fold, dim3(s->Pref), dim3(256), 0, s->stream, s->lin.p, s->Pf, s->Pref, s->N, s->M,
+                               s->torus.p, s->recs[PS_REC_CHAIN][d], negval, stat_scale,
+                               s->rowsum.p + (int64_t)d * s->N, s->rowcnt.p + (int64_t)d * s->N, s->padmax.p + d);
+            PS_HIP(hipGetLastError());
+          }
           if (d == first + count - 1) {   // the run ends here: what the next run (or a hand-over) finds is truncated for real
             hipLaunchKernelGGL(k_truncate_if_flag, dim3(s->Pref), dim3(256), 0, s->stream, s->torus.p, s->Pref, s->N,
                                s->padmax.p + d);

@@ -26,6 +26,9 @@ int rs_launch_row_fwd(int r2, int r3, const RowFwdArgs& a, int npairs, int batch
 int rs_launch_row_inv(int r2, int r3, const RowInvArgs& a, int npairs, int batch, hipStream_t st);
 // mode 0 (nd >= 1 days), 1, 2, 3 as in fft_colfull_kernels.h; lines8 = 128-byte lines per XCD
 int rs_launch_colfull(int r2, int r3, const ColFullArgs& a, int lines8, int batch, hipStream_t st);
+// inverse row pass + fold onto the reference torus (PS_MODE_FOLD; k_row_inv_fold), one workgroup per unit
+struct RowFoldArgs;
+int rs_launch_row_fold(int r2, int r3, const RowFoldArgs& a, int units, hipStream_t st);
 // the single-day pass of this size can take the state column from a pending re-transform (ColFullArgs::alt_src)
 bool rs_colfull_alt_ok(int r2, int r3);
 // two-role chained pass (k_colfull_dual; mode 0, nd >= 2): sizes for which rs_dual_ok

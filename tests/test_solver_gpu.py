@@ -577,7 +577,8 @@ def test_fold_mode_fused_day_is_bit_identical(hip_lib, monkeypatch):
     day pass (k_colfull_day ALT on the row pass of the torus) and a flagged day's truncation inside the next
     row pass (k_row_fwd_rs reads the flag; the torus itself is truncated when the run ends).  Same bits as
     the separate launches (PS_NO_FOLD_FUSE=1), also for a run split in two, with flags on both sides of
-    the split."""
+    the split.  The inverse row pass that folds on chip (k_row_inv_fold, the default) adds rows first and
+    columns second where k_fold adds element by element: equal to round-off, same flags and counts."""
     from parasitoids_amd import synthetic
     monkeypatch.setenv('PS_TPIPE', '1')
     R, K, nd = 400, 401, 10
@@ -585,16 +586,18 @@ def test_fold_mode_fused_day_is_bit_identical(hip_lib, monkeypatch):
     _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
     state = sparse.coo_matrix(([1.0], ([730], [730])), shape=(N, N))
     runs = {}
-    for tag in ('fused', 'separate', 'split'):
+    for tag in ('fused', 'separate', 'split', 'rows', 'rows_split'):
+        monkeypatch.delenv('PS_NO_FOLD_FUSE', raising=False)
+        monkeypatch.delenv('PS_NO_FOLD_ROWS', raising=False)
         if tag == 'separate':
             monkeypatch.setenv('PS_NO_FOLD_FUSE', '1')
-        else:
-            monkeypatch.delenv('PS_NO_FOLD_FUSE', raising=False)
+        if tag in ('fused', 'split'):
+            monkeypatch.setenv('PS_NO_FOLD_ROWS', '1')
         s = hip_lib.HipSolve(state, [K, K], mode='fold', chain_only=True)
         assert s.mode == 'fold' and s.full_column
         s.set_kernels(kernels)
         s.prof_enable(True, every=1)
-        if tag == 'split':
+        if tag.endswith('split'):
             s.run_chain(0, 4, renorm=True)
             s.run_chain(4, nd - 4, renorm=True)
         else:
@@ -606,11 +609,19 @@ def test_fold_mode_fused_day_is_bit_identical(hip_lib, monkeypatch):
         s.close()
     flags = [f for f, _, _, _ in runs['separate'][1]]
     assert sum(flags[:4]) >= 1 and sum(flags[4:]) >= 1 and not all(flags), flags
-    assert runs['separate'][2] == nd and runs['fused'][2] == 0 and runs['split'][2] == 0
+    assert runs['separate'][2] == nd and all(runs[t][2] == 0 for t in ('fused', 'split', 'rows', 'rows_split'))
     for tag in ('fused', 'split'):
         assert runs[tag][1] == runs['separate'][1]
         for a, b in zip(runs[tag][0], runs['separate'][0]):
             assert np.array_equal(a, b)
+    for tag in ('rows', 'rows_split'):
+        for (f, n, sm, dl), (f0, n0, sm0, dl0) in zip(runs[tag][1], runs['separate'][1]):
+            assert (f, n) == (f0, n0) and abs(sm - sm0) < 1e-13 and abs(dl - dl0) < 1e-16
+        for a, b in zip(runs[tag][0], runs['separate'][0]):
+            assert np.abs(a - b).max() < 1e-16
+    assert runs['rows'][1] == runs['rows_split'][1]
+    for a, b in zip(runs['rows'][0], runs['rows_split'][0]):
+        assert np.array_equal(a, b)
 
 
 def test_flag_history_chains_the_quiet_stretches(hip_lib, monkeypatch):
