@@ -1725,13 +1725,15 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     PS_TRY(s->fold_padmax.ensure(1));
     PS_TRY(ensure_temps(s, 1));
     PS_TRY(s->T2.ensure(spec));
-    // Full-column pipeline on a size whose day pass can transform the state column itself (ALT): the day is
-    // row pass of the torus -> day pass (state column + kernel column -> product -> inverse) -> row pass
-    // -> fold; the forward column pass of the state and the truncation of a flagged day's torus are no
-    // launches of their own (the next row pass reads the flag and leaves the pad region out; the torus
-    // itself is truncated once, when the run ends).  PS_NO_FOLD_FUSE=1: A/B knob.
-    const bool fuse = s->tpipe && s->rs_r2 != 0 && rs_colfull_alt_ok(s->rs_r2, s->rs_r3) && getenv("PS_NO_FOLD_FUSE") == nullptr;
-    if (fuse && !s->one_flag.p) {
+    // Full-column pipeline on the register-resident kernels: the day is row pass of the torus -> day pass
+    // (state column + kernel column -> product -> inverse) -> row pass that folds on chip.  The forward
+    // column pass of the state is no launch of its own on sizes whose day pass can transform the state
+    // column itself (ALT; the others keep it), the truncation of a flagged day's torus never is (the next
+    // row pass reads the flag and leaves the pad region out; the torus itself is truncated once, when the
+    // run ends), and k_fold is gone with the M x M field.  PS_NO_FOLD_FUSE=1, PS_NO_FOLD_ALT=1: A/B knobs.
+    const bool fuse = s->tpipe && s->rs_r2 != 0 && getenv("PS_NO_FOLD_FUSE") == nullptr;
+    const bool fuse_alt = fuse && rs_colfull_alt_ok(s->rs_r2, s->rs_r3) && getenv("PS_NO_FOLD_ALT") == nullptr;
+    if (fuse_alt && !s->one_flag.p) {
       PS_TRY(s->one_flag.ensure(1));
       const double one = 1.0;
       PS_HIP(hipMemcpyAsync(s->one_flag.p, &one, sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1748,8 +1750,13 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
                                 d > first ? s->padmax.p + d - 1 : nullptr, s->N));
           RowLive klive = s->kt_live;
           klive.range = s->krange.p + 2 * d;
-          const ColAlt alt{s->T1.p, s->one_flag.p, RowLive{1, tmap, nullptr}};
-          PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr, 1, nullptr, 0, -1, -1, true, &alt));
+          if (fuse_alt) {
+            const ColAlt alt{s->T1.p, s->one_flag.p, RowLive{1, tmap, nullptr}};
+            PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr, 1, nullptr, 0, -1, -1, true, &alt));
+          } else {
+            PS_TRY(launch_colfull(s, 1, s->T1.p, s->Ahat.p, 0, nullptr, 1, RowLive{1, tmap, nullptr}, nullptr));
+            PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr));
+          }
           // inverse row pass and fold in one kernel (the M x M field never goes to HBM) when a torus row
           // folds at most once; PS_NO_FOLD_ROWS=1: A/B knob
           if (s->Pref >= 2 * s->M && getenv("PS_NO_FOLD_ROWS") == nullptr) {

@@ -586,9 +586,13 @@ def test_fold_mode_fused_day_is_bit_identical(hip_lib, monkeypatch):
     _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
     state = sparse.coo_matrix(([1.0], ([730], [730])), shape=(N, N))
     runs = {}
-    for tag in ('fused', 'separate', 'split', 'rows', 'rows_split'):
+    for tag in ('fused', 'separate', 'split', 'no_alt', 'rows', 'rows_split'):
         monkeypatch.delenv('PS_NO_FOLD_FUSE', raising=False)
         monkeypatch.delenv('PS_NO_FOLD_ROWS', raising=False)
+        monkeypatch.delenv('PS_NO_FOLD_ALT', raising=False)
+        if tag == 'no_alt':        # sizes without an ALT day pass (9-wave transforms): forward column pass kept
+            monkeypatch.setenv('PS_NO_FOLD_ALT', '1')
+            monkeypatch.setenv('PS_NO_FOLD_ROWS', '1')
         if tag == 'separate':
             monkeypatch.setenv('PS_NO_FOLD_FUSE', '1')
         if tag in ('fused', 'split'):
@@ -610,7 +614,8 @@ def test_fold_mode_fused_day_is_bit_identical(hip_lib, monkeypatch):
     flags = [f for f, _, _, _ in runs['separate'][1]]
     assert sum(flags[:4]) >= 1 and sum(flags[4:]) >= 1 and not all(flags), flags
     assert runs['separate'][2] == nd and all(runs[t][2] == 0 for t in ('fused', 'split', 'rows', 'rows_split'))
-    for tag in ('fused', 'split'):
+    assert runs['no_alt'][2] == nd
+    for tag in ('fused', 'split', 'no_alt'):
         assert runs[tag][1] == runs['separate'][1]
         for a, b in zip(runs[tag][0], runs['separate'][0]):
             assert np.array_equal(a, b)
