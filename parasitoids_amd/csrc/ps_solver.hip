@@ -1719,7 +1719,6 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // the reference torus up to round-off, on fast FFT sizes.
     const size_t spec = (size_t)s->Pf * s->ld;
     PS_TRY(s->Ahat.ensure(spec));
-    PS_TRY(s->lin.ensure((size_t)s->Pf * s->Pf));
     PS_TRY(s->fold_rowsum.ensure((size_t)s->Pf));
     PS_TRY(s->fold_rowcnt.ensure((size_t)s->Pf));
     PS_TRY(s->fold_padmax.ensure(1));
@@ -1733,6 +1732,10 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // run ends), and k_fold is gone with the M x M field.  PS_NO_FOLD_FUSE=1, PS_NO_FOLD_ALT=1: A/B knobs.
     const bool fuse = s->tpipe && s->rs_r2 != 0 && getenv("PS_NO_FOLD_FUSE") == nullptr;
     const bool fuse_alt = fuse && rs_colfull_alt_ok(s->rs_r2, s->rs_r3) && getenv("PS_NO_FOLD_ALT") == nullptr;
+    // the folding row pass needs a torus row to fold at most once; PS_NO_FOLD_ROWS=1: A/B knob.  Only the
+    // two-kernel form needs the M x M field in memory (564 MB at 8400 points)
+    const bool fold_rows = fuse && s->Pref >= 2 * s->M && getenv("PS_NO_FOLD_ROWS") == nullptr;
+    if (!fold_rows) PS_TRY(s->lin.ensure((size_t)s->Pf * s->Pf));
     if (fuse_alt && !s->one_flag.p) {
       PS_TRY(s->one_flag.ensure(1));
       const double one = 1.0;
@@ -1757,9 +1760,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
             PS_TRY(launch_colfull(s, 1, s->T1.p, s->Ahat.p, 0, nullptr, 1, RowLive{1, tmap, nullptr}, nullptr));
             PS_TRY(launch_colfull(s, 0, B, s->Ahat.p, 0, s->T2.p, 1, klive, nullptr));
           }
-          // inverse row pass and fold in one kernel (the M x M field never goes to HBM) when a torus row
-          // folds at most once; PS_NO_FOLD_ROWS=1: A/B knob
-          if (s->Pref >= 2 * s->M && getenv("PS_NO_FOLD_ROWS") == nullptr) {
+          if (fold_rows) {   // inverse row pass and fold in one kernel
             RowFoldArgs fa;
             fa.src = s->T2.p; fa.ld = s->ld; fa.M = s->Pf; fa.P = s->Pref; fa.N = s->N; fa.m = s->M;
             fa.scale = 1.0 / ((double)s->Pf * (double)s->Pf); fa.negval = negval; fa.stat_scale = stat_scale;
