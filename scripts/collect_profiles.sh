@@ -46,6 +46,9 @@ run pm_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/pm_fetch" -o p --output-fo
 run pm_write --kernel-trace --pmc WRITE_SIZE -d "$out/pm_write" -o p --output-format csv -- \
   python3 "$root/bench_extras.py" prob_mass
 (cd "$root/scripts" && python3 prob_mass_traffic.py "$out/pm_fetch" "$out/pm_write" 11 "$out/prob_mass_hbm_traffic.json") > "$out/prob_mass_hbm_traffic.txt"
+# 4b. a whole Bayes evaluation (18 x prob_mass + 17-day exact-torus chain, R = 400, auto mode): kernel statistics
+run bayes_stats --kernel-trace --stats -d "$out/bayes_stats" -o b --output-format csv -- \
+  python3 "$root/bench_bayes.py" --evals 60 --warmup 5 --no-cpu-baseline
 # 5. one stack launch by launch (start, duration, idle gap before every kernel) from the bench trace
 python3 "$root/scripts/trace_timeline.py" "$out/bench_stats" -150 150 > "$out/stack_timeline.txt" 2>&1 || true
 find "$out" -name "*kernel_stats.csv" | head
