@@ -25,9 +25,9 @@ run bench_stats --kernel-trace --stats -d "$out/bench_stats" -o b --output-forma
   python3 "$root/bench.py" --steps 5 --warmup 2 --no-extras --no-cpu-baseline
 # 2. HBM traffic of the same command
 BENCH_NO_PROF=1 run bench_fetch --kernel-trace --pmc FETCH_SIZE -d "$out/bench_fetch" -o p --output-format csv -- \
-  python3 "$root/bench.py" --steps 2 --warmup 2 --no-extras --no-cpu-baseline
+  python3 "$root/bench.py" --steps 4 --warmup 2 --no-extras --no-cpu-baseline
 BENCH_NO_PROF=1 run bench_write --kernel-trace --pmc WRITE_SIZE -d "$out/bench_write" -o p --output-format csv -- \
-  python3 "$root/bench.py" --steps 2 --warmup 2 --no-extras --no-cpu-baseline
+  python3 "$root/bench.py" --steps 4 --warmup 2 --no-extras --no-cpu-baseline
 python3 "$root/scripts/hbm_traffic.py" "$out/bench_fetch" "$out/bench_write" "$out/bench_hbm_traffic_pmc.json" "$out/provenance.txt" > "$out/bench_hbm_traffic.txt"
 # 3. the real-wind chains (Carnarvon, R = 2048: full-column pipeline, flags, fold path)
 run rw_stats --kernel-trace --stats -d "$out/rw_stats" -o b --output-format csv -- \
