@@ -262,6 +262,58 @@ def test_every_register_resident_size(hip_lib, monkeypatch):
     assert done >= 35
 
 
+def test_every_register_resident_size_in_fold_mode(hip_lib, monkeypatch):
+    """PS_MODE_FOLD, one short chain with a flag per size of fft_rs_sizes.h: the three-launch day (state
+    column transformed inside the day pass where the size has an ALT instance, truncation inside the next
+    row pass, k_row_inv_fold) against the six-launch day of round 2 (PS_NO_FOLD_FUSE=1: separate forward
+    column pass, k_row_inv_rs(p) + k_fold, k_truncate_if_flag).  Rows-then-columns against element-wise
+    sums: round-off; flags and counts equal."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_TPIPE', '1')
+    done = flagged = 0
+    for Lfft in _rs_sizes():
+        m = Lfft // 9
+        K = 2 * m + 1
+        hit = None
+        for dn in range(0, 40, 2):
+            N = Lfft - 3 * m - dn
+            N -= (N + 1) % 2                       # odd domain
+            R = N // 2
+            state = sparse.coo_matrix(([0.6, 0.4], ([R, N - 9], [R, 14])), shape=(N, N))
+            monkeypatch.delenv('PS_NO_FOLD_FUSE', raising=False)
+            s = hip_lib.HipSolve(state, [K, K], mode='fold', chain_only=True)
+            ok = s.fft_len == Lfft and s.full_column
+            if ok:
+                hit = (N, R, state, s)
+                break
+            s.close()
+            if s.fft_len < Lfft:
+                break                              # the next smaller size serves everything below
+        if hit is None:
+            continue
+        N, R, state, s = hit
+        _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=3, seed=Lfft, sigma=(4.0, 9.0), shift=K // 5)
+        res = []
+        for fused in (True, False):
+            if not fused:
+                monkeypatch.setenv('PS_NO_FOLD_FUSE', '1')
+                s = hip_lib.HipSolve(state, [K, K], mode='fold', chain_only=True)
+            s.set_kernels(kernels)
+            s.run_chain(renorm=True)
+            st = s.chain_stats(0, 3)
+            res.append(([s.dense(0, d) for d in range(3)], [(bool(x.flag), x.nnz) for x in st], [x.sum for x in st]))
+            s.close()
+        flagged += any(f for f, _ in res[1][1])
+        assert res[0][1] == res[1][1], Lfft
+        for a, b in zip(res[0][0], res[1][0]):
+            assert np.abs(a - b).max() < 1e-15, Lfft
+        for a, b in zip(res[0][2], res[1][2]):
+            assert abs(a - b) < 1e-13, Lfft
+        done += 1
+    monkeypatch.delenv('PS_NO_FOLD_FUSE', raising=False)
+    assert done >= 35 and flagged >= done // 2, (done, flagged)   # the truncation path ran for most sizes
+
+
 def test_direct_sum_subpass_matches_fft_subpass(hip_lib, monkeypatch):
     """Compact day kernels on a split column transform take the direct-sum first column
     sub-pass inside the fused kernel (kt_direct_fill); PS_NO_DIRECT=1 forces the FFT sub-pass.
