@@ -57,6 +57,7 @@ int rs_rows_set_attrs() {
   return 0;
 }
 
+static int device_cus();
 static int grid_x(int npairs, int np, int tstride) {
   int gx = (npairs + np - 1) / np;
   if (tstride) {   // column-major side: the workgroups sharing a 128-byte line sit on one XCD
@@ -71,6 +72,20 @@ int rs_launch_row_fwd(int r2, int r3, const RowFwdArgs& a, int npairs, int batch
   if (r2 == A && r3 == B) {                                                                                  \
     using C = RsCfg<A, B>;                                                                                   \
     constexpr int np = C::NP;                                                                                \
+    /* small transforms pack 2-4 row pairs into a 12-wave workgroup; a single field with few live rows   \
+       (the 1201-row torus of the R = 400 fold child on 1920 points: 151 workgroups for 256 CUs) then     \
+       leaves CUs idle -- half the pairs per workgroup there */                                             \
+    constexpr int np2 = (np >= 2 && C::S::L <= 2560) ? np / 2 : np;                                          \
+    if constexpr (np2 != np) {                                                                               \
+      const int live = a.rmap.n1 + (a.P > a.rmap.lo2 ? a.P - a.rmap.lo2 : 0);                                \
+      if ((((live + 1) / 2 + np - 1) / np) * batch < device_cus()) {                                         \
+        auto k2 = k_row_fwd_rs<16, A, B, np2>;                                                               \
+        using Y2 = RsInvLds<16, A, B>;                                                                       \
+        constexpr size_t lds2 = Y2::bytes(np2);                                                              \
+        hipLaunchKernelGGL(k2, dim3(grid_x(npairs, np2, a.tstride), batch), dim3(C::S::NTHR * np2), lds2, st, a); \
+        return 1;                                                                                            \
+      }                                                                                                      \
+    }                                                                                                        \
     auto kern = k_row_fwd_rs<16, A, B, np>;                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid_x(npairs, np, a.tstride), batch), dim3(C::S::NTHR * np), C::LDS, st, a); \
     return 1;                                                                                                \
