@@ -164,6 +164,30 @@ __device__ __forceinline__ int pm_support(const BvuRule& R, double sdx, double s
   return hmax;
 }
 
+// The same search for FOUR windows per wave: lane group g = lane / 16 looks for its own window's h
+// among base + (lane & 15), 16 candidates a step (a typical support is 15-30 cells: 64 candidates per
+// window and step mostly evaluated squares nobody needed).  Same result as pm_support: the smallest h
+// that passes, hmax if none does.  Groups with `active` false take no part and get 0.
+__device__ __forceinline__ int pm_support16(const BvuRule& R, double sdx, double sdy, double mux,
+                                            double muy, double cell, int hmax, bool active) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  int found = active ? -1 : 0;
+  for (int base = 0; base <= hmax; base += 16) {
+    const int h = base + sub;
+    bool ok = false;
+    if (found < 0) {
+      const double e = (h + 0.5) * cell;
+      const double p = pm_rect(R, sdx, sdy, mux, muy, -e, e, -e, e);
+      ok = (h <= hmax) && (1 - p < 0.001);
+    }
+    const unsigned long long m = __ballot(ok);
+    const unsigned gm = (unsigned)((m >> (16 * grp)) & 0xffffull);
+    if (found < 0 && gm) found = base + __ffs((int)gm) - 1;
+    if (__ballot(found < 0) == 0ull) break;
+  }
+  return found < 0 ? hmax : found;
+}
+
 // ---------------------------------------------------------------- h_flight_prob
 // ParasitoidModel.py:282-309 with f_time_prob :243-267 and g_wind_prob :231-240.
 // One block per day; the two cumulative sums run sequentially like np.cumsum.
@@ -256,15 +280,16 @@ __global__ void k_hprob(const double* __restrict__ wind, ModelParams mp, const i
 
 // ---------------------------------------------------------------- per period
 // advection, residual mean, window centre, support (ParasitoidModel.py:439-499).
-// One wave per (day, period).
+// Sixteen lanes per (day, period): a wave takes four periods (pm_support16).
 __global__ void k_periods(const double* __restrict__ wind, const int* __restrict__ day_keys,
                           ModelParams mp, const int* day_idx, const double* start_time,
                           const double* hprob, PeriodInfo* pinfo) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int T = mp.T;
   const int d = blockIdx.y;
-  if (wave >= T) return;
-  const int t = wave;
+  if (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 >= T) return;   // whole wave beyond the day
+  const bool valid = grp < T;          // the last wave of a day may hold fewer than four periods
+  const int t = valid ? grp : T - 1;
   const int di = day_idx[d];
   const double* dw = wind + (int64_t)di * T * 3;
   PeriodInfo pi;
@@ -330,8 +355,8 @@ __global__ void k_periods(const double* __restrict__ wind, const int* __restrict
   pi.muy = my - ry * c;
   pi.cc = mp.rad_res + (int)rint(mx / c);
   pi.rc = mp.rad_res + (int)rint(-my / c);
-  pi.H = pi.skip ? 0 : pm_support(mp.rule, mp.sdx, mp.sdy, pi.mux, pi.muy, c, 4 * mp.rad_res + 64);
-  if ((threadIdx.x & 63) == 0) pinfo[(int64_t)d * T + t] = pi;
+  pi.H = pm_support16(mp.rule, mp.sdx, mp.sdy, pi.mux, pi.muy, c, 4 * mp.rad_res + 64, valid && !pi.skip);
+  if (valid && (threadIdx.x & 15) == 0) pinfo[(int64_t)d * T + t] = pi;
 }
 
 // per day: losses in period order (ParasitoidModel.py:541-558), hprob bounds

@@ -206,7 +206,7 @@ static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const dou
   hipLaunchKernelGGL(k_hprob, dim3(nd), dim3(256), (size_t)3 * T * sizeof(double), st, m->wind.p, mp, m->day_idx.p,
                      m->hprob.p, m->scratch.p);
   PS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_periods, dim3((T * 64 + 255) / 256, nd), dim3(256), 0, st, m->wind.p, m->day_keys.p, mp,
+  hipLaunchKernelGGL(k_periods, dim3((T * 16 + 255) / 256, nd), dim3(256), 0, st, m->wind.p, m->day_keys.p, mp,
                      m->day_idx.p, m->start_time.p, m->hprob.p, m->pinfo.p);
   PS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_day_prep, dim3(nd), dim3(256), (size_t)T * (sizeof(PeriodInfo) + sizeof(double)), st, mp, m->start_time.p,
