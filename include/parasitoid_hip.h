@@ -140,7 +140,10 @@ int ps_chain_set_kernels(ps_solver* s, int nk, const int64_t* off, const int32_t
                          const int32_t* row, const int32_t* col, const double* val);
 /* Run days [first, first+count) from the current state: per day
  * fftconv2 -> ifft2 -> statistics/flag -> (flagged) truncate + re-FFT, all enqueued on
- * the handle's stream without host synchronisation.  Day d's field is chain record d.
+ * the handle's stream.  The flag decisions are taken on the device; the call itself waits for
+ * the device only where it verifies a window of days that it ran without the conditional
+ * launches (it returns with the last window verified).  Day d's field is chain record d; the
+ * statistics of every day run since the kernels were uploaded stay readable (ps_chain_stats).
  * A run may be continued (first > 0 right after a run that ended at first) in PS_MODE_EXACT / FAST /
  * FOLD.  PS_MODE_AUTO runs need a fresh state (ps_solver_set_state_*) before EVERY call: once a run
  * has handed days over to its helpers the front solver's spectrum is void, and whether that happened
