@@ -89,6 +89,15 @@ int ps_solver_destroy(ps_solver* s);
 /* P = reference torus, Pfft = transform size in use, H = Pfft/2+1 */
 int ps_solver_info(ps_solver* s, int* dom_len, int* P, int* Pfft, int* H);
 int ps_solver_sync(ps_solver* s);
+/* Tuning / A-B knobs.  The reference has one switch (globalvars.py:5: `cuda`); this library's
+ * knobs (csrc/ps_config.h) exist for measurements and for the A/B legs of
+ * the bit-identity tests.  Their names are those of the environment variables that seed them: the
+ * environment is read once, when a handle is created, and never again -- afterwards a knob of a
+ * live handle is changed with these calls (an auto-mode front passes it on to its helpers).
+ * Creation-time knobs (register-resident kernels on/off, column split, chunk size ...) are refused
+ * with PS_ERR_STATE, unknown names with PS_ERR_BAD_ARG. */
+int ps_solver_set_option(ps_solver* s, const char* key, double value);
+int ps_solver_get_option(ps_solver* s, const char* key, double* value);
 /* measurement aid: 1 when the day kernels of the last transformed chunk were compact enough
  * for the direct-sum first column sub-pass inside the fused kernel (no separate launch) */
 int ps_solver_kernels_direct(ps_solver* s);
@@ -203,6 +212,7 @@ int ps_weighted_sum(ps_solver* s, int n, const int32_t* kind, const int32_t* idx
 int ps_prof_enable(ps_solver* s, int on);   /* 0 off, 1 every launch, n > 1 every n-th launch per class */
 int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* count); /* synchronises */
 int ps_prof_read_days(ps_solver* s, int ncls, int64_t* days); /* grid-days of the timed launches per class */
+int ps_prof_read_launches(ps_solver* s, int ncls, int64_t* launches); /* ALL launches per class since ps_prof_enable (timed or not) */
 
 /* full P x P complex spectrum in/out (function-level CalcSol.fft2/fftconv2/ifft2 mirrors;
  * only valid in PS_MODE_EXACT) */
@@ -214,6 +224,9 @@ int ps_solver_set_spectrum(ps_solver* s, const double* in /* P*P*2 */);
  *      get_mvn_cdf_values (:311-380) ---- */
 int ps_model_create(ps_model** out, int device);
 int ps_model_destroy(ps_model* m);
+/* "PS_PM_SEG" (periods summed per prob_mass record, 8) and "PS_PM_SYNC" (1: never size the pair
+ * lists from the previous batch); see ps_solver_set_option */
+int ps_model_set_option(ps_model* m, const char* key, double value);
 /* wind: float64 [ndays_wind][T][3] (windx, windy, windr), rows in the order of the
  * sorted day keys; day_keys[ndays_wind] the integer keys (prob_mass looks up day+1).
  * T == 1 rows with test_run != 0 reproduce the single-period mode (:422-428). */

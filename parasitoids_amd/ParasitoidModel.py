@@ -170,6 +170,10 @@ class WindModel():
                                             self.T, int(self.test_run)))
         self.last = None
 
+    def set_option(self, key, value):
+        '''PS_PM_SEG / PS_PM_SYNC of this model handle (read from the environment when it was created)'''
+        L.check(self._lib.ps_model_set_option(self._h, key.encode(), float(value)))
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             self._lib.ps_model_destroy(self._h)

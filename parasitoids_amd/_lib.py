@@ -59,6 +59,8 @@ SIGNATURES = {
     'ps_solver_destroy': (C.c_int, [_VP]),
     'ps_solver_info': (C.c_int, [_VP, _I32P, _I32P, _I32P, _I32P]),
     'ps_solver_sync': (C.c_int, [_VP]),
+    'ps_solver_set_option': (C.c_int, [_VP, C.c_char_p, C.c_double]),
+    'ps_solver_get_option': (C.c_int, [_VP, C.c_char_p, _F64P]),
     'ps_solver_set_state_coo': (C.c_int, [_VP, _I32P, _I32P, _F64P, C.c_int64]),
     'ps_solver_fftconv2_coo': (C.c_int, [_VP, _I32P, _I32P, _F64P, C.c_int64, C.c_int]),
     'ps_solver_get_cursol': (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.POINTER(DayStats)]),
@@ -88,10 +90,12 @@ SIGNATURES = {
     'ps_prof_enable': (C.c_int, [_VP, C.c_int]),
     'ps_prof_read': (C.c_int, [_VP, C.c_int, _F64P, _I64P]),
     'ps_prof_read_days': (C.c_int, [_VP, C.c_int, _I64P]),
+    'ps_prof_read_launches': (C.c_int, [_VP, C.c_int, _I64P]),
     'ps_solver_get_spectrum': (C.c_int, [_VP, _F64P]),
     'ps_solver_set_spectrum': (C.c_int, [_VP, _F64P]),
     'ps_model_create': (C.c_int, [C.POINTER(_VP), C.c_int]),
     'ps_model_destroy': (C.c_int, [_VP]),
+    'ps_model_set_option': (C.c_int, [_VP, C.c_char_p, C.c_double]),
     'ps_model_set_wind': (C.c_int, [_VP, _F64P, _I32P, C.c_int, C.c_int, C.c_int]),
     'ps_model_prob_mass': (C.c_int, [_VP, C.c_int, _I32P, _F64P, _F64P, _F64P, _F64P, C.c_double,
                                      C.c_int, C.c_double, C.c_int, _I32P, _I64P, _I32P, _I32P]),

@@ -9,9 +9,11 @@
 #include "chain_kernels.h"
 #include "model_kernels.h"
 #include "ps_common.h"
+#include "ps_config.h"
 
 struct ps_model {
   int device = 0;
+  ps_config cfg;   // PS_PM_SEG / PS_PM_SYNC as ps_model_create found them, then ps_model_set_option
   hipStream_t stream = nullptr;
   // wind
   DevBuf<double> wind;
@@ -95,6 +97,7 @@ extern "C" int ps_model_create(ps_model** out, int device) {
   PS_HIP(hipFuncSetAttribute((const void*)k_day_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   PS_HIP(hipFuncSetAttribute((const void*)k_hprob, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   ps_model* m = new ps_model();
+  ps_config_from_env(&m->cfg);   // the only look at the environment a model handle takes
   m->device = device;
   hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -102,6 +105,12 @@ extern "C" int ps_model_create(ps_model** out, int device) {
     return ps_fail(PS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   *out = m;
+  return PS_OK;
+}
+
+extern "C" int ps_model_set_option(ps_model* m, const char* key, double value) {
+  if (!m || !key) return ps_fail(PS_ERR_BAD_ARG, "model set_option: bad arguments");
+  if (ps_config_set(&m->cfg, key, value, false) != 0) return ps_fail(PS_ERR_BAD_ARG, "model set_option: unknown option %s", key);
   return PS_OK;
 }
 
@@ -225,7 +234,7 @@ static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const dou
     PS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, m->tcnt.p, (int)ntot, m->toff.p);
     PS_HIP(hipGetLastError());
-    static const int seg = getenv("PS_PM_SEG") ? std::max(1, atoi(getenv("PS_PM_SEG"))) : 8;   // periods per record
+    const int seg = std::max(1, m->cfg.pm_seg);   // periods per record
     const long long max_pairs = (long long)1 << 20;   // 2 GB of records per chunk
     // The pair lists' length is known on the device only.  A batch like the previous one (sampler
     // chains, ensemble members: same days, nearby parameters) sizes its lists from that one's count
@@ -239,7 +248,7 @@ static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const dou
     if (key != m->guess_key) { m->guess_key = key; m->max_np = 0; m->last_np = 0; }
     const long long cap = std::max(m->last_np + m->last_np / 4, m->max_np) + 4096;
     bool guessed = false;
-    if (allow_guess && m->last_np > 0 && cap <= max_pairs && getenv("PS_PM_SYNC") == nullptr) {
+    if (allow_guess && m->last_np > 0 && cap <= max_pairs && !m->cfg.pm_sync) {
       guessed = true;
       PS_TRY(m->np_dev.ensure(1));
       if (!m->np_host) PS_HIP(hipHostMalloc((void**)&m->np_host, sizeof(long long), hipHostMallocDefault));

@@ -8,6 +8,7 @@
 #include "fft_colfull_kernels.h"   // ColFullArgs (the kernels are instantiated in ps_colfull.hip)
 #include "rs_launch.h"
 #include "ps_common.h"
+#include "ps_config.h"
 
 thread_local std::string ps_tls_error;
 
@@ -173,7 +174,8 @@ struct ps_solver {
   // pass 264 -> 237 us, chained 218 -> 186 us per day, but the row pass 145 -> 252 us (32-byte
   // pieces at a column's stride per lane): a net loss, so the column pass keeps its 16-byte
   // row-major stores.  It also shows what those stores cost the day pass: 27 us of 264.
-  bool tinv = getenv("PS_TINV") ? atoi(getenv("PS_TINV")) != 0 : false;
+  bool tinv = false;
+  ps_config cfg;   // knobs of this handle: the environment as ps_solver_create found it, then ps_solver_set_option
   // The state's spectrum is built lazily from its spatial record (PS_REC_STATE), in the layout
   // of the pipeline the first consumer picks: ps_chain_run takes the tiled pipeline for compact
   // day kernels (multi-day fused passes with direct-sum kernels) and the full-column one
@@ -183,7 +185,7 @@ struct ps_solver {
   int num_cu = 256;
   // flag speculation in ps_chain_run: on until this solver has seen a boundary flag
   bool speculate = true;
-  int fused_days = getenv("PS_FUSED_DAYS") ? atoi(getenv("PS_FUSED_DAYS")) : 8;   // days per fused column pass (1, 2, 4, 8)
+  int fused_days = 8;   // days per fused column pass (1, 2, 4, 8)
   int spec_window = 1;
   hipEvent_t spec_ev[2] = {nullptr, nullptr};
   // second stream: the kernel transforms of the later days of a chunk run there, behind the
@@ -193,7 +195,7 @@ struct ps_solver {
   int kt_from = -1;
   // auto mode, front solver: kernels from this day on are transformed only if the run gets there
   // (the previous run left the front at its first unclean day); -1 = nothing pending
-  int kt_lazy_from = -1, kt_lazy_c0 = 0, kt_lazy_cn = 0;
+  int kt_lazy_from = -1, kt_lazy_c0 = 0, kt_lazy_cn = 0, kt_lazy_direct = 0;
   unsigned long long* hflags = nullptr;   // pinned host copy of the pad maxima
   int hflags_n = 0;
   // ... and of the previous chain run's, copied behind it and read when the next run starts: a solver that
@@ -334,17 +336,14 @@ static int row_pairs(const FftProg& P) {
   rp = std::max(1, std::min(8, rp));
   return rp;
 }
-static int col_wsh(int L) {
+static int col_wsh(const ps_solver* s, int L) {
   int w = 4096 / std::max(1, L);
   int sh = 2;
   while ((1 << (sh + 1)) <= w && sh < 5) ++sh;
-  if (const char* e = getenv("PS_COL_WSH")) sh = atoi(e);   // tuning knob (tile width 2^sh columns)
+  if (s->cfg.col_wsh >= 0) sh = s->cfg.col_wsh;   // tuning knob (tile width 2^sh columns)
   return sh;
 }
-static int col_threads() {
-  if (const char* e = getenv("PS_COL_THREADS")) return atoi(e);   // tuning knob
-  return 256;
-}
+static int col_threads(const ps_solver* s) { return s->cfg.col_threads; }   // tuning knob
 
 // register-resident kernel families: rs_launch.h (instantiated in ps_rs_rows.hip / ps_colfull.hip)
 static int set_lds_attr() {
@@ -393,7 +392,7 @@ static int launch_row_fwd(ps_solver* s, const double* src, int64_t src_bstride, 
   const size_t lds = ((size_t)a.rp * row_pitch(a.prog) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   if (lds > (size_t)kMaxLds) return ps_fail(PS_ERR_UNSUPPORTED, "row pass needs %zu B LDS", lds);
   ProfScope prof(s, pred ? PS_PROF_REFFT : PS_PROF_ROW_FWD);
-  if (s->rs_r2 != 0 && getenv("PS_NO_RS_FWD") == nullptr) {
+  if (s->rs_r2 != 0 && !s->cfg.no_rs_fwd) {
     if (!rs_launch_row_fwd(s->rs_r2, s->rs_r3, a, npairs, batch, s->stream))
       return ps_fail(PS_ERR_STATE, "no register-resident row kernel for 16 x %d x %d", s->rs_r2, s->rs_r3);
   } else if (s->row_plan.generic)
@@ -416,7 +415,7 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   a.src_bstride = bs; a.src2_bstride = src2_bstride; a.prod_bstride = bs; a.dst_bstride = bs;
   a.ld = s->ld; a.ncols = s->H;
   a.prog = cp.plan->prog;
-  a.wsh = col_wsh(a.prog.L);
+  a.wsh = col_wsh(s, a.prog.L);
   a.n_outer = cp.n_outer;
   a.in_base_mul = cp.in_base_mul; a.in_stride = cp.in_stride;
   a.out_base_mul = cp.out_base_mul; a.out_stride = cp.out_stride;
@@ -441,17 +440,16 @@ static int launch_col(ps_solver* s, const ColPass& cp, const cplx* src, const cp
   ProfScope prof(s, pred ? PS_PROF_REFFT
                           : (DIR == PS_FWD ? PS_PROF_COL_FWD_A : PS_PROF_COL_INV_A) + (cp.second ? 1 : 0));
   if (cp.plan->generic)
-    hipLaunchKernelGGL((k_col<DIR, true>), grid, dim3(col_threads()), lds, s->stream, a);
+    hipLaunchKernelGGL((k_col<DIR, true>), grid, dim3(col_threads(s)), lds, s->stream, a);
   else
-    hipLaunchKernelGGL((k_col<DIR, false>), grid, dim3(col_threads()), lds, s->stream, a);
+    hipLaunchKernelGGL((k_col<DIR, false>), grid, dim3(col_threads(s)), lds, s->stream, a);
   PS_HIP(hipGetLastError());
   return PS_OK;
 }
 
 // the persistent row kernel serves this solver's size (and is not switched off)
 static bool row_inv_persistent(const ps_solver* s) {
-  const char* e = getenv("PS_RSP");   // A/B knob: 0 never, 1 wherever it exists (read per launch: tests flip it)
-  const int knob = e ? atoi(e) : -1;
+  const int knob = s->cfg.rsp;   // A/B knob: 0 never, 1 wherever it exists, -1 the rule below
   RsInfo info;
   if (s->rs_r2 == 0 || !rs_info(s->rs_r2, s->rs_r3, &info) || !info.rsp || knob == 0) return false;
   // The tiled pipeline hands each day's spectrum over through the Infinity Cache (215 MB written by
@@ -523,8 +521,7 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
 // (src -> state), 2 inverse (state -> dst), 3 product only (state *= FFT(src))
 // does a mode-0 launch of nd days go to the two-role chained pass?
 static bool colfull_dual(const ps_solver* s, int nd) {
-  const char* e = getenv("PS_DUAL_MIN_DAYS");   // A/B knob, read per launch (tests flip it); 0 = never
-  const int dual_min = e ? atoi(e) : 6;
+  const int dual_min = s->cfg.dual_min_days;   // A/B knob; 0 = never
   return dual_min > 0 && nd >= dual_min && rs_dual_ok(s->rs_r2, s->rs_r3);
 }
 
@@ -654,8 +651,7 @@ static int fwd2d_partial(ps_solver* s, const double* src, int64_t src_bstride, i
 
 static void fused_direct_args(ps_solver* s, ColFusedArgs& a) {
   a.direct = s->kt_direct ? 1 : 0;
-  static const int no_conj = getenv("PS_NO_CONJ") ? 1 : 0;
-  a.no_conj = no_conj;
+  a.no_conj = s->cfg.no_conj;
   a.tp_lo = s->tp_lo.p; a.tp_hi = s->tp_hi.p; a.tp_shift = s->tp_shift;
   a.mgL2 = ps_magic((uint32_t)a.L2);
 }
@@ -680,8 +676,8 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   fused_direct_args(s, a);
   // 16-column tiles: the fused pass keeps four tile transfers in flight per workgroup, and
   // twice as many (smaller) workgroups per CU beat the 512-byte segments of W = 32 (+1.7 %)
-  a.wsh = std::min(col_wsh(a.prog.L), 4);
-  if (const char* e = getenv("PS_FUSED_WSH")) a.wsh = atoi(e);   // tuning knob
+  a.wsh = std::min(col_wsh(s, a.prog.L), 4);
+  if (s->cfg.fused_wsh >= 0) a.wsh = s->cfg.fused_wsh;   // tuning knob
   auto need = [&](int wsh) {
     return (((size_t)a.prog.L << wsh) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
            (size_t)(a.prog.L + 4) * sizeof(int) + fused_direct_lds(a);
@@ -692,7 +688,7 @@ static int launch_col_fused(ps_solver* s, const cplx* kt, cplx* state, int store
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * a.L1), 1);   // see fused_tile_map
   ProfScope prof(s, PS_PROF_COL_INV_A);
-  static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
+  const int fthr = s->cfg.fused_threads > 0 ? s->cfg.fused_threads : col_threads(s);   // tuning knob
   if (plan->generic)
     hipLaunchKernelGGL(k_col_fused<true>, grid, dim3(fthr), need(a.wsh), s->stream, a);
   else
@@ -722,12 +718,12 @@ static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* st
   fused_direct_args(s, a);
   const int ndsh = nd == 1 ? 0 : nd == 2 ? 1 : (nd == 4 ? 2 : 3);
   // direct mode: two outer indices per workgroup halve the re-reads of the live rows
-  static const int gopt = getenv("PS_FUSED_G") ? atoi(getenv("PS_FUSED_G")) : 2;   // tuning knob
+  const int gopt = s->cfg.fused_g;   // tuning knob
   const int G = (a.direct && gopt == 2 && a.L1 % 2 == 0) ? 2 : 1;
   const int gsh = G == 2 ? 1 : 0;
   // 8-column tiles for four or more days: 37 KB of LDS per workgroup keeps four of them on a CU
-  a.wsh = std::min(col_wsh(a.prog.L), nd >= 4 ? 3 : 4);
-  if (const char* e = getenv("PS_MULTI_WSH")) a.wsh = atoi(e);   // tuning knob
+  a.wsh = std::min(col_wsh(s, a.prog.L), nd >= 4 ? 3 : 4);
+  if (s->cfg.multi_wsh >= 0) a.wsh = s->cfg.multi_wsh;   // tuning knob
   auto need = [&](int wsh) {
     return (((size_t)a.prog.L << (wsh + ndsh + gsh)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx) +
            (size_t)(a.prog.L + 4) * sizeof(int) + G * fused_direct_lds(a) +
@@ -743,8 +739,8 @@ static int launch_col_fused_multi(ps_solver* s, const cplx* kt, int nd, cplx* st
   dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * (a.L1 / G)), 1);   // see fused_tile_map
   ProfScope prof(s, nd == 1 ? PS_PROF_COL_INV_A : nd == 2 ? PS_PROF_COL_INV_A2 : nd == 4 ? PS_PROF_COL_INV_A4 : PS_PROF_COL_INV_A8);
   // the paired tile (74 KB at two or four days) leaves two workgroups per CU: 512 threads each keep 16 waves there
-  static const int fenv = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : 0;   // tuning knob
-  const int fthr = fenv ? fenv : (G == 2 && nd > 1 ? 512 : col_threads());
+  const int fenv = s->cfg.fused_threads;   // tuning knob
+  const int fthr = fenv > 0 ? fenv : (G == 2 && nd > 1 ? 512 : col_threads(s));
 #define PS_MULTI_LAUNCH(ND, GG)                                                                                          \
   if (plan->generic) hipLaunchKernelGGL((k_col_fused_multi<true, ND, GG>), grid, dim3(fthr), need(a.wsh), s->stream, a); \
   else hipLaunchKernelGGL((k_col_fused_multi<false, ND, GG>), grid, dim3(fthr), need(a.wsh), s->stream, a)
@@ -784,19 +780,19 @@ static int launch_col_fused_dual(ps_solver* s, const cplx* kt, const cplx* state
   a.prog = plan->prog;
   a.dst_dstride = 0;
   fused_direct_args(s, a);   // never direct in PS_MODE_FOLD (transform_kernels)
-  a.wsh = std::min(col_wsh(a.prog.L), 4);
-  if (const char* e = getenv("PS_DUAL_WSH")) a.wsh = atoi(e);   // tuning knob
+  a.wsh = std::min(col_wsh(s, a.prog.L), 4);
+  if (s->cfg.dual_wsh >= 0) a.wsh = s->cfg.dual_wsh;   // tuning knob
   auto need = [&](int wsh) {
     return (((size_t)a.prog.L << (wsh + 1)) + a.prog.n_lo + a.prog.n_hi + a.prog.n_gen) * sizeof(cplx);
   };
   while (need(a.wsh) > (size_t)kMaxLds && a.wsh > 2) --a.wsh;
   *done = 0;
-  if (need(a.wsh) > (size_t)kMaxLds || getenv("PS_NO_DUAL")) return PS_OK;
+  if (need(a.wsh) > (size_t)kMaxLds || s->cfg.no_dual) return PS_OK;
   const int W = 1 << a.wsh;
   const int ntiles = (s->H + W - 1) / W;
   dim3 grid((unsigned)((a.direct ? (ntiles + 7) / 8 * 8 : ntiles) * a.L1), 1);   // see fused_tile_map
   ProfScope prof(s, PS_PROF_COL_INV_A);
-  static const int fthr = getenv("PS_FUSED_THREADS") ? atoi(getenv("PS_FUSED_THREADS")) : col_threads();   // tuning knob
+  const int fthr = s->cfg.fused_threads > 0 ? s->cfg.fused_threads : col_threads(s);   // tuning knob
   if (plan->generic)
     hipLaunchKernelGGL(k_col_fused_dual<true>, grid, dim3(fthr), need(a.wsh), s->stream, a);
   else
@@ -812,7 +808,7 @@ static int conv_inv(ps_solver* s, const cplx* kt, cplx* state, int store_prod, d
   if (s->tpipe) {
     RowLive live = s->kt_live;
     live.range = rowrange;
-    static const int split2 = getenv("PS_TPIPE_SPLIT") ? atoi(getenv("PS_TPIPE_SPLIT")) : 0;   // A/B knob
+    const int split2 = s->cfg.tpipe_split;   // A/B knob
     if (split2 && store_prod) {
       // two passes at <= 128 registers (two workgroups per CU each) instead of one at 162:
       // product into the state, then the inverse of the state.  Measured: 2 x 159 us against
@@ -844,12 +840,12 @@ static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, dou
     if (!colfull_chains(s)) return PS_OK;
     RowLive live = s->kt_live;
     live.range = rowrange;
-    const bool batched_rows = row_inv_persistent(s) && !s->tinv && nd <= PS_MAX_GROUP_DAYS && getenv("PS_NO_ROW_BATCH") == nullptr;
+    const bool batched_rows = row_inv_persistent(s) && !s->tinv && nd <= PS_MAX_GROUP_DAYS && !s->cfg.no_row_batch;
     // The two-role pass also sums |x|^2 over the pad-only rows of every day's intermediate; when even
     // that total cannot lift one row pair to the flag threshold, the row pass leaves the pad-only
     // pairs (21 % of the rows at N = 4097 on 5184) unread -- the per-pair Parseval test it would
     // otherwise make after fetching them, decided for the whole day.  PS_NO_PAD_QUIET=1: A/B knob.
-    const bool quiet = batched_rows && colfull_dual(s, nd) && s->N + 1 < s->Pf && getenv("PS_NO_PAD_QUIET") == nullptr;
+    const bool quiet = batched_rows && colfull_dual(s, nd) && s->N + 1 < s->Pf && !s->cfg.no_pad_quiet;
     if (quiet) {
       PS_TRY(s->pad_energy.ensure((size_t)nd * s->H));
       PS_TRY(s->pad_quiet.ensure(PS_MAX_GROUP_DAYS));
@@ -865,7 +861,7 @@ static int conv_inv_multi(ps_solver* s, const cplx* kt, int nd, cplx* state, dou
       int v = 0;
       if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess) s->ncu = v;
     }
-    if (colfull_dual(s, nd) && s->ncu > 0 && s->H > s->ncu && !s->tinv && getenv("PS_NO_TAIL_SPLIT") == nullptr) {
+    if (colfull_dual(s, nd) && s->ncu > 0 && s->H > s->ncu && !s->tinv && !s->cfg.no_tail_split) {
       const int rem = s->H % s->ncu;
       if (rem > 0 && rem * 3 <= s->ncu) hmain = s->H - rem;
     }
@@ -975,21 +971,17 @@ static int resolve_refft(ps_solver* s) {
 // fast-mode FFT size for a reference pad P: the smallest even 7-smooth size, or a size served
 // by the register-resident row kernels (row passes 35-50 % faster) when that costs at most
 // 8 % more work
-static int fast_size(int Pref) {
-  if (const char* e = getenv("PS_FAST_SIZE")) {   // experiments: force the fast torus (must be >= the reference pad)
-    const int f = atoi(e);
-    if (f >= Pref) return f;
-  }
+static int fast_size(const ps_config& cfg, int Pref) {
+  if (cfg.fast_size >= Pref) return cfg.fast_size;   // experiments: force the fast torus (must be >= the reference pad)
   int Pf = ps_next_fast_len(Pref);
-  if (getenv("PS_NO_RS") == nullptr) {
+  if (!cfg.no_rs) {
     const int L = rs_next_size(Pref);
     // ... or whenever the 7-smooth size is beyond the LDS-resident row limit (~9700)
     // (PS_RS_AREA: A/B knob for the accepted area ratio)
     // Below 2048 points the tiled kernels of an awkward 7-smooth size (1372 = 28 x 49 for the R = 512
     // Bayes chain: a split column transform with tiny sub-transforms) lose far more than 20 % of area
     // costs: measured 1.05 M -> 1.37 M samples/hour (fast mode) with 1.2.
-    static const double area_env = getenv("PS_RS_AREA") ? atof(getenv("PS_RS_AREA")) : 0.0;
-    const double area = area_env > 0.0 ? area_env : (Pf < 2048 ? 1.2 : 1.08);
+    const double area = cfg.rs_area > 0.0 ? cfg.rs_area : (Pf < 2048 ? 1.2 : 1.08);
     if (L > 0 && ((double)L * L <= area * (double)Pf * Pf || Pf > 9700)) Pf = L;
   }
   return Pf;
@@ -997,11 +989,22 @@ static int fast_size(int Pref) {
 
 extern "C" int ps_fast_size(int dom_len, int max_shape) {
   if (dom_len < 1 || max_shape < 1) return 0;
-  return fast_size(dom_len + max_shape / 2);
+  // a query without a handle: the knobs a solver created now would start from
+  ps_config cfg;
+  ps_config_from_env(&cfg);
+  return fast_size(cfg, dom_len + max_shape / 2);
 }
 
 // ------------------------------------------------------------------- create
+static int solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode, const ps_config& cfg);
+
 extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode) {
+  ps_config cfg;
+  ps_config_from_env(&cfg);   // the only look at the environment a solver ever takes
+  return solver_create(out, device, dom_len, max_shape, mode, cfg);
+}
+
+static int solver_create(ps_solver** out, int device, int dom_len, int max_shape, int mode, const ps_config& cfg) {
   if (!out) return ps_fail(PS_ERR_BAD_ARG, "null output handle");
   *out = nullptr;
   if (dom_len < 1 || max_shape < 1) return ps_fail(PS_ERR_BAD_SHAPE, "dom_len=%d max_shape=%d", dom_len, max_shape);
@@ -1012,6 +1015,9 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   PS_TRY(ps_use_device(device));
   PS_TRY(set_lds_attr());
   ps_solver* s = new ps_solver();
+  s->cfg = cfg;
+  s->tinv = cfg.tinv != 0;
+  s->fused_days = cfg.fused_days;
   s->device = device;
   s->N = dom_len;
   s->M = max_shape / 2;
@@ -1019,9 +1025,9 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
   s->mode = mode;
   s->auto_exact = auto_exact;
   if (auto_exact) s->pad_floor = 0.5 * kCleanEps;
-  s->Pf = mode == PS_MODE_FAST ? fast_size(s->Pref) : s->Pref;
+  s->Pf = mode == PS_MODE_FAST ? fast_size(cfg, s->Pref) : s->Pref;
   // fold mode: room for the whole linear convolution, P + K - 1 = N + 3 (K//2)
-  if (mode == PS_MODE_FOLD) s->Pf = fast_size(s->Pref + 2 * s->M);
+  if (mode == PS_MODE_FOLD) s->Pf = fast_size(cfg, s->Pref + 2 * s->M);
   s->H = s->Pf / 2 + 1;
   s->ld = (s->H + 7) & ~7;
   auto fail = [&](int rc) {
@@ -1033,7 +1039,7 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     HostFftPlan small, big;
     const bool ok_s = ps_build_plan(s->Pf, true, &small), ok_b = ps_build_plan(s->Pf, true, &big, true);
     if (ok_s && ok_b && small.max_prime <= 9 && s->Pf > 1024 && big.prog.ns < small.prog.ns &&
-        getenv("PS_NO_BIG_RADIX") == nullptr) {
+        !cfg.no_big_radix) {
       s->row_plan.host = big;
       s->row_big = true;
     }
@@ -1043,29 +1049,25 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
                         s->Pf, PS_MAX_GENERIC_RADIX));
   {
     int r2 = 0, r3 = 0;
-    const bool rs = getenv("PS_NO_RS") == nullptr && rs_lookup(s->Pf, &r2, &r3);   // rows stay in registers
+    const bool rs = !cfg.no_rs && rs_lookup(s->Pf, &r2, &r3);   // rows stay in registers
     if (!rs && (size_t)(row_pitch(s->row_plan.host.prog) + 512) * sizeof(cplx) > (size_t)kMaxLds)
       return fail(ps_fail(PS_ERR_UNSUPPORTED, "pad size %d exceeds the LDS-resident row limit", s->Pf));
   }
   int rc = s->row_plan.upload();
   if (rc) return fail(rc);
-  if (getenv("PS_NO_RS") == nullptr && !rs_lookup(s->Pf, &s->rs_r2, &s->rs_r3)) s->rs_r2 = s->rs_r3 = 0;
-  s->tpipe_ok = (mode == PS_MODE_FAST || mode == PS_MODE_FOLD) && s->rs_r2 != 0 && getenv("PS_NO_RS") == nullptr &&
-                getenv("PS_NO_RS_FWD") == nullptr && getenv("PS_NO_TPIPE") == nullptr;
-  if (mode == PS_MODE_FOLD && getenv("PS_NO_FOLD_TPIPE")) s->tpipe_ok = false;   // A/B knob
+  if (cfg.no_rs || !rs_lookup(s->Pf, &s->rs_r2, &s->rs_r3)) s->rs_r2 = s->rs_r3 = 0;
+  s->tpipe_ok = (mode == PS_MODE_FAST || mode == PS_MODE_FOLD) && s->rs_r2 != 0 && !cfg.no_rs &&
+                !cfg.no_rs_fwd && !cfg.no_tpipe;
+  if (mode == PS_MODE_FOLD && cfg.no_fold_tpipe) s->tpipe_ok = false;   // A/B knob
   s->tpipe = s->tpipe_ok;   // fold mode: always the full-column pipeline when its size allows (no compact-kernel route there)
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) s->num_cu = ncu;
   }
   {
-    static const int single_max = getenv("PS_COL_SINGLE_MAX") ? atoi(getenv("PS_COL_SINGLE_MAX")) : 1200;   // tuning knob
-    s->L1 = ps_choose_col_split(s->Pf, single_max);
+    s->L1 = ps_choose_col_split(s->Pf, cfg.col_single_max);   // tuning knob
   }
-  if (const char* e = getenv("PS_COL_L1")) {   // tuning knob: first sub-pass length of the column split
-    const int l1 = atoi(e);
-    if (l1 > 1 && l1 < s->Pf && s->Pf % l1 == 0) s->L1 = l1;
-  }
+  if (cfg.col_l1 > 1 && cfg.col_l1 < s->Pf && s->Pf % cfg.col_l1 == 0) s->L1 = cfg.col_l1;   // tuning knob: first sub-pass length of the column split
   s->split = s->L1 != s->Pf;
   if (s->split) {
     s->L2 = s->Pf / s->L1;
@@ -1107,7 +1109,7 @@ extern "C" int ps_solver_create(ps_solver** out, int device, int dom_len, int ma
     if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mtotal / 16 > budget) budget = mtotal / 16;
   }
   s->chunk_days = (int)std::max<size_t>(1, std::min<size_t>(64, budget / (spec * sizeof(cplx))));
-  if (const char* e = getenv("PS_CHUNK_DAYS")) s->chunk_days = std::max(1, atoi(e));   // tuning knob
+  if (cfg.chunk_days > 0) s->chunk_days = cfg.chunk_days;   // tuning knob
   if ((rc = s->Ahat.ensure(spec))) return fail(rc);
   if ((rc = s->rowoff.ensure(s->N))) return fail(rc);
   if ((rc = ensure_stats(s, 4))) return fail(rc);
@@ -1328,11 +1330,11 @@ extern "C" int ps_solver_set_state_coo(ps_solver* s, const int32_t* row, const i
 // compact day kernels (few live rows per residue class of the column split) can take the
 // direct-sum first column sub-pass of the tiled pipeline (kt_direct_fill)
 static bool direct_possible(const ps_solver* s) {
-  return s->split && s->mode != PS_MODE_FOLD && getenv("PS_NO_DIRECT") == nullptr &&
+  return s->split && s->mode != PS_MODE_FOLD && !s->cfg.no_direct &&
          s->L1 <= 255 && s->L2 <= 255;   // kt_direct_entry packs term indices in bytes
 }
 static bool day_is_compact(const ps_solver* s, int d) {
-  static const int max_terms = getenv("PS_DIRECT_MAX_TERMS") ? atoi(getenv("PS_DIRECT_MAX_TERMS")) : 8;   // tuning knob
+  const int max_terms = s->cfg.direct_max_terms;   // tuning knob
   const int M = s->Kmax / 2;
   const int lo = s->hkrange[2 * d], hi = s->hkrange[2 * d + 1];
   if (lo > hi) return true;
@@ -1345,7 +1347,9 @@ static bool day_is_compact(const ps_solver* s, int d) {
 // transform `count` kernels starting at day `first` into Bhat[0..count)
 // The transforms go to slots [slot0, slot0 + count) of buffers sized for `total` slots (a chunk
 // transformed in two parts: the second part on the second stream).
-static int transform_kernels(ps_solver* s, int first, int count, int slot0, int total) {
+// `direct`: -1 decide from these days; 0 / 1 the caller decided for the whole chunk (a chunk
+// transformed in two calls must hold ONE format: kt_direct / kt_live are solver-wide)
+static int transform_kernels(ps_solver* s, int first, int count, int slot0, int total, int direct_chunk) {
   const int K = s->Kmax, M = K / 2;
   const size_t spec = (size_t)s->Pf * s->ld;
   if (total < 0) total = count;
@@ -1385,7 +1389,8 @@ static int transform_kernels(ps_solver* s, int first, int count, int slot0, int 
   // near 8 terms at FFT size 5760; the fold-mode fused pass, with the state in the other half of
   // its tile, does not gain)
   bool direct = direct_possible(s);
-  for (int d = first; d < first + count && direct; ++d) direct = day_is_compact(s, d);
+  if (direct_chunk >= 0) direct = direct && direct_chunk != 0;
+  else for (int d = first; d < first + count && direct; ++d) direct = day_is_compact(s, d);
   PS_TRY(fwd2d_partial(s, kd, (int64_t)K * K, K, map_wrap(M, s->Pf), map_wrap(M, s->Pf), s->Bhat.p + (size_t)slot0 * spec, count,
                        s->krange.p + 2 * first, direct));
   s->bhat_first = first - slot0;
@@ -1394,12 +1399,12 @@ static int transform_kernels(ps_solver* s, int first, int count, int slot0, int 
 }
 
 // main stream: wait for the second stream's kernel transforms before day `d` is used
-static int transform_kernels(ps_solver* s, int first, int count, int slot0 = 0, int total = -1);
+static int transform_kernels(ps_solver* s, int first, int count, int slot0 = 0, int total = -1, int direct_chunk = -1);
 static int kernels_ready(ps_solver* s, int d) {
   if (s->kt_lazy_from >= 0 && d >= s->kt_lazy_from) {
     const int from = s->kt_lazy_from, done = from - s->kt_lazy_c0;
     s->kt_lazy_from = -1;
-    PS_TRY(transform_kernels(s, from, s->kt_lazy_cn - done, done, s->kt_lazy_cn));
+    PS_TRY(transform_kernels(s, from, s->kt_lazy_cn - done, done, s->kt_lazy_cn, s->kt_lazy_direct));
   }
   if (s->kt_from >= 0 && d >= s->kt_from) {
     PS_HIP(hipStreamWaitEvent(s->stream, s->kt_ev, 0));
@@ -1532,7 +1537,7 @@ int ps_chain_adopt_device_kernels(ps_solver* s, int nk, const int64_t* off, cons
 static int auto_attach(ps_solver* s, ps_solver** slot, int mode, int max_shape, bool* kernels_ok, int end) {
   if (!*slot) {
     ps_solver* c = nullptr;
-    PS_TRY(ps_solver_create(&c, s->device, s->N, max_shape, mode));
+    PS_TRY(solver_create(&c, s->device, s->N, max_shape, mode, s->cfg));   // the parent's knobs, not the environment's
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
     c->stream = s->stream;
@@ -1599,9 +1604,9 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   // a solver per kernel-shape class is not rebuilt all the time: big grids (Carnarvon R = 2048
   // rad_dist 10 km: 495 -> 570 grid-days/s; the R = 400 sampler, whose kernel extent moves with
   // every proposal, ran 2x SLOWER with it).  PS_WIDE_MIN_N: smallest domain that uses it.
-  const int wide_min_n = getenv("PS_WIDE_MIN_N") ? atoi(getenv("PS_WIDE_MIN_N")) : 1500;   // read per call: tests switch it
-  const bool no_wide = getenv("PS_NO_WIDE") != nullptr || s->N < wide_min_n;   // fold child for everything
-  static const int kWin = getenv("PS_AUTO_WINDOW") ? std::min(64, std::max(1, atoi(getenv("PS_AUTO_WINDOW")))) : 4;
+  const int wide_min_n = s->cfg.wide_min_n;
+  const bool no_wide = s->cfg.no_wide || s->N < wide_min_n;   // fold child for everything
+  const int kWin = std::min(64, std::max(1, s->cfg.auto_window));
   if ((int)s->owner.size() < end) s->owner.resize(end, 0);
   for (int d = first; d < f; ++d) s->owner[d] = 0;
   enum { WIDE = 1, CHILD = 2 };
@@ -1732,11 +1737,11 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // column itself (ALT; the others keep it), the truncation of a flagged day's torus never is (the next
     // row pass reads the flag and leaves the pad region out; the torus itself is truncated once, when the
     // run ends), and k_fold is gone with the M x M field.  PS_NO_FOLD_FUSE=1, PS_NO_FOLD_ALT=1: A/B knobs.
-    const bool fuse = s->tpipe && s->rs_r2 != 0 && getenv("PS_NO_FOLD_FUSE") == nullptr;
-    const bool fuse_alt = fuse && rs_colfull_alt_ok(s->rs_r2, s->rs_r3) && getenv("PS_NO_FOLD_ALT") == nullptr;
+    const bool fuse = s->tpipe && s->rs_r2 != 0 && !s->cfg.no_fold_fuse;
+    const bool fuse_alt = fuse && rs_colfull_alt_ok(s->rs_r2, s->rs_r3) && !s->cfg.no_fold_alt;
     // the folding row pass needs a torus row to fold at most once; PS_NO_FOLD_ROWS=1: A/B knob.  Only the
     // two-kernel form needs the M x M field in memory (564 MB at 8400 points)
-    const bool fold_rows = fuse && s->Pref >= 2 * s->M && getenv("PS_NO_FOLD_ROWS") == nullptr;
+    const bool fold_rows = fuse && s->Pref >= 2 * s->M && !s->cfg.no_fold_rows;
     if (!fold_rows) PS_TRY(s->lin.ensure((size_t)s->Pf * s->Pf));
     if (fuse_alt && !s->one_flag.p) {
       PS_TRY(s->one_flag.ensure(1));
@@ -1845,7 +1850,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     return PS_OK;
   }
   s->spec_window = 2;   // 2 + 4 + 8 = one chunk of 14 days, all of them in multi-day fused passes
-  if (getenv("PS_NO_SPECULATION")) s->speculate = false;
+  if (s->cfg.no_speculation) s->speculate = false;
   // A solver whose previous run went through without a flag (sampler chains and ensemble members re-run
   // the same solver on new kernels) does not feel its way 2, 4, 8, ...: it opens with windows of up to
   // PS_MAX_GROUP_DAYS = 32 days (a 30-day run: one window), each ONE chained full-column
@@ -1873,7 +1878,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
   // flags of the previous run over the same days (see `guided` below)
   std::vector<char> hist;
   if (!s->auto_exact && !s->speculate && s->hist_count == count && s->hist_first == first && count >= 2 &&
-      getenv("PS_NO_FLAG_HISTORY") == nullptr && getenv("PS_NO_SPECULATION") == nullptr) {
+      !s->cfg.no_flag_history && !s->cfg.no_speculation) {
     PS_HIP(hipEventSynchronize(s->hist_ev));
     hist.resize(count);
     for (int i = 0; i < count; ++i) {
@@ -1908,18 +1913,17 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // persistent row kernel and the pipelined kernel fetch: 10.5 against 11.7 ms per 30-day stack at 5184,
     // 8.2 against 9.4 at 4608 (single-pass column sizes too: +6 % on the flag-heavy R = 400 Bayes chain).
     bool want = !(s->split && compact) || colfull_chains(s);
-    if (const char* e = getenv("PS_TPIPE")) want = atoi(e) != 0;   // A/B knob
+    if (s->cfg.tpipe >= 0) want = s->cfg.tpipe != 0;   // A/B knob
     set_pipeline(s, want);
   }
   PS_TRY(ensure_spectrum(s));
-  if (s->speculate && s->tpipe && colfull_chains(s) && hint >= count && count >= 4 && getenv("PS_NO_WINDOW_HINT") == nullptr) {
+  if (s->speculate && s->tpipe && colfull_chains(s) && hint >= count && count >= 4 && !s->cfg.no_window_hint) {
     // windows of up to PS_MAX_GROUP_DAYS days, the whole run if it fits.  Measured on the 30-day stack
     // (PS_FIRST_WINDOW): 6 / 8 / 10 / 15 days first and the rest behind -- with the later windows'
     // kernel transforms on the low-priority stream -- 7.98 ms each, one 30-day window 7.84: the idle
     // slot of a second chained pass and the launches saved outweigh the 0.2 ms of kernel transforms
     // that are no longer hidden.
-    const char* fw = getenv("PS_FIRST_WINDOW");   // tuning knob
-    int w0 = fw ? atoi(fw) : count;
+    int w0 = s->cfg.first_window > 0 ? s->cfg.first_window : count;   // tuning knob
     w0 = std::max(2, std::min(std::min(w0, count), PS_MAX_GROUP_DAYS));
     s->spec_window = w0;
     hinted = true;
@@ -1938,10 +1942,9 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     // are transformed ahead of the day passes; the rest go to a second, low-priority stream and
     // run in the CUs the day passes leave idle -- a chained pass has 2593 columns for 256 CUs, its
     // eleventh round occupies 33 of them -- instead of 0.2 ms up front.
-    const char* kts = getenv("PS_KT_SPLIT");                     // A/B knob (per run: tests flip it): 0 = off
-    const int split_days = kts ? atoi(kts) : (hinted ? s->spec_window : 14);   // = the first window(s)
+    const int split_days = s->cfg.kt_split >= 0 ? s->cfg.kt_split : (hinted ? s->spec_window : 14);   // = the first window(s); A/B knob: 0 = off
     const bool lazy_tail = s->auto_exact && hint_abs >= c0 && hint_abs + 2 < c0 + cn &&
-                           getenv("PS_NO_LAZY_KT") == nullptr;   // see the branch below (A/B knob)
+                           !s->cfg.no_lazy_kt;   // see the branch below (A/B knob)
     if (!lazy_tail && s->tpipe && s->speculate && split_days > 0 && cn >= split_days + (hinted ? 4 : 8)) {
       if (!s->stream2) {
         int lo = 0, hi = 0;
@@ -1967,8 +1970,12 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       // spectra of the kernels behind it (29 kernels at 5600 points are 2.6 ms of a 47 ms Carnarvon
       // chain, 17 at 1120 points a twentieth of a Bayes evaluation); kernels_ready transforms the
       // rest if the run stays clean for longer
+      // (one format for the whole chunk, decided over all its days: the two halves share kt_direct / kt_live)
       const int now = hint_abs + 2 - c0;
-      PS_TRY(transform_kernels(s, c0, now, 0, cn));
+      bool direct_all = direct_possible(s);
+      for (int q = c0; q < c0 + cn && direct_all; ++q) direct_all = day_is_compact(s, q);
+      s->kt_lazy_direct = direct_all ? 1 : 0;
+      PS_TRY(transform_kernels(s, c0, now, 0, cn, s->kt_lazy_direct));
       s->kt_lazy_from = c0 + now;
       s->kt_lazy_c0 = c0;
       s->kt_lazy_cn = cn;
@@ -1983,7 +1990,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
       if (with_refft) {
         // full-column pipeline: only the row half now, the column half inside the next day's pass
         // (PS_NO_DEFER_REFFT=1: A/B knob)
-        const bool defer = getenv("PS_NO_DEFER_REFFT") == nullptr && getenv("PS_TPIPE_SPLIT") == nullptr;   // per day: tests flip it
+        const bool defer = !s->cfg.no_defer_refft && !s->cfg.tpipe_split;
         if (s->tpipe && defer && rs_colfull_alt_ok(s->rs_r2, s->rs_r3)) PS_TRY(refft_rows_if_flag(s, rec, d));
         else PS_TRY(refft_if_flag(s, rec, s->Ahat.p, d));
       }
@@ -2007,7 +2014,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
         for (; d < c0 + cn; ++d) PS_TRY(day(d, true));
         break;
       }
-      static const size_t depth = getenv("PS_SPEC_DEPTH") ? (size_t)atoi(getenv("PS_SPEC_DEPTH")) : 2;
+      const size_t depth = (size_t)std::max(1, s->cfg.spec_depth);
       // auto mode: stop enqueueing right after the day that was the first unclean one last time
       // until its check is in -- the days behind it are likely to be redone by the fold path
       while (q.size() < depth && d < c0 + cn && !(hint_abs >= 0 && d == hint_abs + 1 && !q.empty())) {
@@ -2028,9 +2035,9 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
         for (int i = 0; i < w;) {
           int g = 0;
           // direct mode pairs outer indices (twice the tile): four days per pass there
-          static const int direct_days = getenv("PS_DIRECT_DAYS") ? atoi(getenv("PS_DIRECT_DAYS")) : 4;   // tuning knob
+          const int direct_days = s->cfg.direct_days;   // tuning knob
           // (the full-column pipeline chains the days with the state column in registers)
-          static const int tpipe_days = getenv("PS_TPIPE_DAYS") ? atoi(getenv("PS_TPIPE_DAYS")) : PS_MAX_GROUP_DAYS;   // tuning knob
+          const int tpipe_days = std::min(PS_MAX_GROUP_DAYS, std::max(1, s->cfg.tpipe_days));   // tuning knob
           const int maxd = s->tpipe ? std::min(s->fused_days >= 8 ? PS_MAX_GROUP_DAYS : s->fused_days, tpipe_days)
                                     : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
           if (maxd > 1 && w - i >= 2) {
@@ -2087,7 +2094,7 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
     }
   }
   if (s->speculate && flagged_at < 0) s->noflag_hint = count;
-  if (!s->auto_exact && !s->speculate && count >= 2 && getenv("PS_NO_FLAG_HISTORY") == nullptr) {
+  if (!s->auto_exact && !s->speculate && count >= 2 && !s->cfg.no_flag_history) {
     if (s->hhist_n < count) {
       if (s->hist_ev) PS_HIP(hipEventSynchronize(s->hist_ev));   // an earlier run's copy may still be on its way
       if (s->hhist) (void)hipHostFree(s->hhist);
@@ -2204,7 +2211,7 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
   // the back-solve statistics live in their own slots after the call; reuse slots [0,nfilt)
   PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
   PS_HIP(hipMemsetAsync(s->padmax.p, 0, (size_t)std::max(1, nfilt) * sizeof(unsigned long long), s->stream));
-  static const bool no_cache = getenv("PS_NO_FILTER_CACHE") != nullptr;   // A/B knob
+  const bool no_cache = s->cfg.no_filter_cache != 0;   // A/B knob
   // at most 32 cached filters, fewer when a spectrum is large (4 GB in total)
   const size_t kMaxFilt = std::max<size_t>(4, std::min<size_t>(32, ((size_t)4 << 30) / (spec * sizeof(cplx))));
   for (int i = nfilt - 1; i >= 0; --i) {
@@ -2486,6 +2493,26 @@ extern "C" int ps_solver_set_spectrum(ps_solver* s, const double* in) {
   return PS_OK;
 }
 
+// ------------------------------------------------------------------- options
+extern "C" int ps_solver_set_option(ps_solver* s, const char* key, double value) {
+  if (!s || !key) return ps_fail(PS_ERR_BAD_ARG, "set_option: bad arguments");
+  const int rc = ps_config_set(&s->cfg, key, value, true);
+  if (rc == -1) return ps_fail(PS_ERR_BAD_ARG, "set_option: unknown option %s", key);
+  if (rc == -2) return ps_fail(PS_ERR_STATE, "set_option: %s takes effect when a solver is created", key);
+  s->tinv = s->cfg.tinv != 0;
+  s->fused_days = s->cfg.fused_days;
+  // the helpers of an auto-mode front follow their parent
+  if (s->child) PS_TRY(ps_solver_set_option(s->child, key, value));
+  if (s->wide) PS_TRY(ps_solver_set_option(s->wide, key, value));
+  return PS_OK;
+}
+
+extern "C" int ps_solver_get_option(ps_solver* s, const char* key, double* value) {
+  if (!s || !key || !value) return ps_fail(PS_ERR_BAD_ARG, "get_option: bad arguments");
+  if (ps_config_get(&s->cfg, key, value) != 0) return ps_fail(PS_ERR_BAD_ARG, "get_option: unknown option %s", key);
+  return PS_OK;
+}
+
 // ----------------------------------------------------------------- profiling
 static int prof_drain(ps_solver* s) {
   PS_HIP(hipStreamSynchronize(s->stream));
@@ -2529,6 +2556,16 @@ extern "C" int ps_prof_read_days(ps_solver* s, int ncls, int64_t* days) {
   PS_HIP(hipSetDevice(s->device));
   PS_TRY(prof_drain(s));
   for (int i = 0; i < ncls; ++i) days[i] = i < PS_PROF_NCLS ? s->prof_days[i] : 0;
+  return PS_OK;
+}
+
+extern "C" int ps_prof_read_launches(ps_solver* s, int ncls, int64_t* launches) {
+  if (!s || !launches) return ps_fail(PS_ERR_BAD_ARG, "prof_read_launches: bad arguments");
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(prof_drain(s));
+  // the multi-day classes are all timed; of the others every prof_every-th launch is, prof_seen counts all
+  for (int i = 0; i < ncls; ++i)
+    launches[i] = i >= PS_PROF_NCLS ? 0 : (i >= PS_PROF_COL_INV_A2 ? s->prof_cnt[i] : s->prof_seen[i]);
   return PS_OK;
 }
 

@@ -290,6 +290,17 @@ class HipSolve():
     def sync(self):
         L.check(self._lib.ps_solver_sync(self._h))
 
+    def set_option(self, key, value):
+        '''Change a tuning / A-B knob of this solver (names as the environment
+        variables that seed a new solver, e.g. 'PS_RSP').  The library reads the environment only
+        when a solver is created.'''
+        L.check(self._lib.ps_solver_set_option(self._h, key.encode(), float(value)))
+
+    def get_option(self, key):
+        v = C.c_double()
+        L.check(self._lib.ps_solver_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     @property
     def full_column(self):
         '''True when the solver runs the full-column pipeline -- measurement aid.'''
@@ -340,6 +351,13 @@ class HipSolve():
         days = np.zeros(n, dtype=np.int64)
         L.check(self._lib.ps_prof_read_days(self._h, n, L.p_i64(days)))
         return {k: int(days[i]) for i, k in enumerate(self.PROF_CLASSES)}
+
+    def prof_launches(self):
+        '''-> {class: all launches since prof_enable}, timed or not'''
+        n = len(self.PROF_CLASSES)
+        cnt = np.zeros(n, dtype=np.int64)
+        L.check(self._lib.ps_prof_read_launches(self._h, n, L.p_i64(cnt)))
+        return {k: int(cnt[i]) for i, k in enumerate(self.PROF_CLASSES)}
 
     def get_spectrum(self):
         P = self.fft_len

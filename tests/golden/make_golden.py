@@ -4,7 +4,7 @@
 Run in the build container only (it imports /root/reference, which does not
 exist on the GPU box):
 
-    python tests/golden/make_golden.py [group ...]     # groups: g1 .. g9, g5b
+    python tests/golden/make_golden.py [group ...]     # groups: g1 .. g9, g5b, g6b
 
 Three harness-side shims, none of which touch the
 reference: (1) scipy 1.15 no longer exposes `scipy.stats.mvn`; the same Genz
@@ -255,6 +255,73 @@ def g5b():
     save('g5b_prob_mass_large', **out)
 
 
+def _sol_digest(prefix, M, out, count):
+    """A full-size solution day as nnz, sum, pattern SHA-256 and about `count` evenly spaced
+    entries (coo_digest's form with the spacing derived from nnz)."""
+    every = max(1, M.nnz // count)
+    coo_digest(prefix, M, out, every)
+
+
+def g6b():
+    """BASELINE config 3 on real wind at full size: the reference's `prob_mass` for
+    30 Carnarvon days at R = 2048 and its `get_solutions` (CalcSol.py:140-201, CPU branch) at
+    rad_dist 10 km (C3a: flags fire) and 40 km (C3b).  Stored per kernel and per solution day as
+    digests (shape, nnz, sum, SHA-256 of the (row, col) pattern in entry order, ~400 evenly spaced
+    entries), plus per chain day the flag `ifft2` returned and samples / sum / min of the raw field
+    it was computed from (recorded by wrapping the reference's own `ifft2`; nothing is replayed).
+    The release day is a full-day kernel (no start time), as in bench_extras.real_wind_case."""
+    import time
+    out = {}
+    wc, dc = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+    R, nd = 2048, 30
+    N = 2 * R + 1
+    out['days'] = np.array(dc[:nd], dtype=np.int64)
+    pos = np.vstack([sample_positions(N, 3000, 61),
+                     R + np.random.default_rng(62).integers(-300, 301, size=(1000, 2))])
+    out['pos'] = pos
+    for tag, rd in (('c3b', 40000.0), ('c3a', 10000.0)):
+        t0 = time.time()
+        args = [(d, wc, HP, DP, DLP, MU_R, NPER, rd, R) for d in dc[:nd]]
+        with Pool(8) as pool:
+            pmfs = pool.map(_pm, args, chunksize=1)
+        print(tag, 'prob_mass', round(time.time() - t0), 's', flush=True)
+        ms = _max_shape(pmfs)
+        out[tag + '_max_shape'] = ms
+        for i, p in enumerate(pmfs):
+            _sol_digest('%s_pmf%d' % (tag, i), p, out, 400)
+        raw = []
+        real_ifft2 = CS.ifft2
+
+        def spy(A_hat, dom_shape):
+            A, flag = real_ifft2(A_hat, dom_shape)
+            C = A.tocsr()
+            raw.append((bool(flag), np.asarray(C[pos[:, 0], pos[:, 1]]).ravel(),
+                        float(A.data.sum()), float(A.data.min()), float(A.data.max())))
+            return A, flag
+
+        CS.ifft2 = spy
+        try:
+            modelsol = [_recentre(pmfs[0], R)]
+            t0 = time.time()
+            quiet(CS.get_solutions, modelsol, pmfs, dc, nd, N, ms)
+        finally:
+            CS.ifft2 = real_ifft2
+        print(tag, 'get_solutions', round(time.time() - t0), 's', 'flags',
+              ''.join('1' if r[0] else '0' for r in raw), flush=True)
+        assert len(raw) == nd - 1 and len(modelsol) == nd
+        out[tag + '_flags'] = np.array([r[0] for r in raw])
+        out[tag + '_rawsamp'] = np.array([r[1] for r in raw])
+        out[tag + '_rawsum'] = np.array([r[2] for r in raw])
+        out[tag + '_rawmin'] = np.array([r[3] for r in raw])
+        out[tag + '_rawmax'] = np.array([r[4] for r in raw])
+        for i, s in enumerate(modelsol):
+            _sol_digest('%s_sol%d' % (tag, i), s, out, 400)
+            C = s.tocsr()
+            out['%s_solsamp%d' % (tag, i)] = np.asarray(C[pos[:, 0], pos[:, 1]]).ravel()
+        # checkpoint after each variant: the run takes tens of CPU-minutes
+        save('g6b_config3_full', **out)
+
+
 def _kalbar_pmfs(R, nd):
     wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
     args = [(d, wd, HP, DP, DLP, MU_R, NPER, 10000.0, R) for d in days[:nd]]
@@ -445,7 +512,7 @@ def g9():
     save('g9_bayes_funcs', **out)
 
 
-GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g5b': g5b, 'g6': g6, 'g7': g7, 'g8': g8, 'g9': g9}
+GROUPS = {'g1': g1, 'g2': g2, 'g3': g3, 'g5': g5, 'g5b': g5b, 'g6': g6, 'g6b': g6b, 'g7': g7, 'g8': g8, 'g9': g9}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(GROUPS)

@@ -715,3 +715,103 @@ def test_second_stream_kernel_transforms_change_nothing(hip_lib, monkeypatch):
         flags = [f for f, _, _, _ in runs['upfront'][0][1]]
         seen_flags.append(flags.index(1) if 1 in flags else -1)
     assert seen_flags[0] == -1 and any(f >= 8 for f in seen_flags) and any(0 <= f < 8 for f in seen_flags), seen_flags
+
+
+def test_options_are_frozen_per_handle(hip_lib, monkeypatch):
+    """The library reads its PS_* environment once, in ps_solver_create; after that the handle's own
+    table is all it looks at and ps_solver_set_option changes it (the reference has
+    one switch, globalvars.py:5).  An environment change behind a live solver does nothing; the same
+    knob set through the call switches the route between two runs of ONE solver, bit-identically;
+    creation-time knobs and unknown names are refused."""
+    from parasitoids_amd import synthetic
+    from parasitoids_amd._lib import HipError, PS_ERR_STATE, PS_ERR_BAD_ARG
+    monkeypatch.setenv('PS_TPIPE', '1')
+    monkeypatch.setenv('PS_RSP', '1')
+    R, K, nd = 400, 401, 16
+    N = 2 * R + 1
+    _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
+    state = sparse.coo_matrix(([1.0], ([400], [400])), shape=(N, N))
+    s = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+    assert s.get_option('PS_RSP') == 1 and s.get_option('PS_TPIPE') == 1
+    s.set_kernels(kernels)
+
+    def run():
+        s.set_state(state)
+        s.prof_enable(True, every=1)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        prof = s.prof_read()
+        batched = sum(prof[k][1] for k in ('row_inv_x2', 'row_inv_x4', 'row_inv_x8', 'row_inv_xn'))
+        return [s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st], batched
+
+    s.set_option('PS_NO_WINDOW_HINT', 1)       # every run ramps 2, 4, 8, 2: comparable launch counts
+    a = run()
+    assert a[2] >= 3
+    monkeypatch.setenv('PS_RSP', '0')          # behind the solver's back: no effect
+    monkeypatch.setenv('PS_NO_ROW_BATCH', '1')
+    b = run()
+    assert b[2] == a[2]
+    s.set_option('PS_NO_ROW_BATCH', 1)         # through the call: one row launch per day
+    c = run()
+    assert c[2] == 0
+    s.set_option('PS_RSP', 0)                  # ... and the one-shot row kernel
+    d = run()
+    assert d[2] == 0 and s.get_option('PS_RSP') == 0
+    for r in (b, c, d):
+        assert r[1] == a[1]
+        for x, y in zip(r[0], a[0]):
+            assert np.array_equal(x, y)
+    for key, code in (('PS_NO_RS', PS_ERR_STATE), ('PS_COL_L1', PS_ERR_STATE), ('PS_NO_SUCH_KNOB', PS_ERR_BAD_ARG)):
+        with pytest.raises(HipError) as e:
+            s.set_option(key, 1)
+        assert e.value.code == code
+    s.close()
+    # a solver created now starts from the environment as it is now
+    s2 = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True)
+    assert s2.get_option('PS_RSP') == 0 and s2.get_option('PS_NO_ROW_BATCH') == 1
+    s2.close()
+
+
+def test_lazy_kernel_transforms_keep_one_format_per_chunk(hip_lib, monkeypatch):
+    """an auto-mode front whose previous run handed over at day h transforms only
+    the kernels up to day h + 1 up front and the rest when the run gets there (`lazy_tail`).  On the
+    TILED pipeline the two halves of such a chunk must share one format -- `kt_direct` / `kt_live` are
+    solver-wide -- even when the early days are compact (direct-sum first column sub-pass) and a late
+    day is broad.  A size without register-resident kernels (PS_NO_RS), compact kernels on days 0-7 and
+    broad ones behind: first run from the edge (hands over early), second from the centre (stays clean
+    past the lazily transformed days).  Bit-identical to PS_NO_LAZY_KT=1, and right against the oracle."""
+    from parasitoids_amd import synthetic
+    monkeypatch.setenv('PS_NO_RS', '1')
+    R, K, nd = 700, 401, 12
+    N = 2 * R + 1
+    _, narrow, _ = synthetic.make_stack(R=R, K=K, ndays=8, seed=5, sigma=(2.5, 3.5), shift=3)
+    _, broad, _ = synthetic.make_stack(R=R, K=K, ndays=nd - 8, seed=6, sigma=(45.0, 60.0), shift=3)
+    kernels = narrow + broad
+    pt = lambda c: sparse.coo_matrix(([1.0], ([c], [c])), shape=(N, N))
+    edge, centre = pt(N - 1 - 40), pt(R)
+    ms = np.array([K, K])
+    ref, trace = [centre], {}
+    OC.get_solutions(ref, [None] + kernels, list(range(nd + 1)), nd + 1, N, ms, trace=trace)
+    out = {}
+    for tag in ('lazy', 'upfront'):
+        s = hip_lib.HipSolve(edge, ms, mode='auto', chain_only=True)
+        assert s.mode == 'auto' and not s.full_column
+        s.set_option('PS_DIRECT_MAX_TERMS', 4)     # narrow: 2 terms per output, broad: >= 8 (any column split)
+        if tag == 'upfront':
+            s.set_option('PS_NO_LAZY_KT', 1)
+        s.set_kernels(kernels)
+        s.run_chain(renorm=True)
+        h = s.auto_info()[0]
+        assert 1 <= h <= 5, h                       # handed over while the kernels were still the narrow ones
+        s.set_state(centre)
+        s.run_chain(renorm=True)
+        st = s.chain_stats(0, nd)
+        h2 = s.auto_info()[0]
+        assert h2 == -1 or h2 >= 9, h2              # the front consumed lazily transformed (broad) days
+        out[tag] = [s.dense(0, d) for d in range(nd)]
+        for d in range(nd):
+            np.testing.assert_allclose(out[tag][d], trace['raw'][d], rtol=0, atol=1e-13)
+            assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
+        s.close()
+    for a, b in zip(out['lazy'], out['upfront']):
+        assert np.array_equal(a, b)
