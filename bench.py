@@ -45,7 +45,7 @@ MODEL_P2 = {
 DAYS_PER_LAUNCH = {'col_inv_a_x2': 2, 'col_inv_a_x4': 4, 'col_inv_a_x8': 8,
                    'row_inv_x2': 2, 'row_inv_x4': 4, 'row_inv_x8': 8}
 # `_xn`: any other number of chained days per launch (a solver whose previous run raised no flag opens
-# with windows of up to 16 days: 15 + 15 for this stack); the library counts the grid-days its timed
+# with windows of up to 32 days: one 30-day window for this stack); the library counts the grid-days its timed
 # launches covered (ps_prof_read_days) and main() fills in the average
 VARIABLE_DAYS = ('col_inv_a_xn', 'row_inv_xn')
 # kernel class -> (kernel symbol prefixes in the rocprofv3 PMC summaries under profiles/, days per
@@ -77,6 +77,47 @@ def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0, days=None):
         return nd * (S + F)
     return {'col_inv_b': 2 * S, 'col_fwd_a': 2 * S, 'col_fwd_b': 2 * S,
             'row_fwd': None, 'refft_pred': None}.get(cls)
+
+
+def chain_compulsory_bytes(N, K, fl, nd, kernels, per_step, kern, num_cu=256):
+    """Compulsory HBM bytes of ONE stack as this implementation launches it: the sum over
+    launch classes of `launch_bytes` x launches per step, plus what the classes without a byte model move
+    -- kernel staging (zeroed band, scatter, row pass of the live rows), `set_state` (record memset +
+    the state's column pass) and the short launches for the columns taken out of a chained pass.
+    `per_step`: {class: launches per step}; `kern`: the per-class table with `bytes_per_launch`."""
+    ld = (fl // 2 + 1 + 7) // 8 * 8
+    H = fl // 2 + 1
+    S = fl * ld * 16.0
+    F = N * N * 8.0
+    parts = {}
+    for k, n in per_step.items():
+        b = kern.get(k, {}).get('bytes_per_launch')
+        if b and n:
+            parts[k] = n * b
+    live = [(int(k.row.max()) - int(k.row.min()) + 1) if k.nnz else 0 for k in kernels]
+    nnz = sum(int(k.nnz) for k in kernels)
+    # staging block: zero the live band, scatter the triplets, row pass reads the band and writes live rows x H
+    parts['kernel_staging'] = sum(live) * K * 8.0 * 2 + nnz * 24.0 + sum(live) * H * 16.0
+    parts['set_state'] = F + S
+    rem = H % num_cu
+    if 0 < rem * 3 <= num_cu and per_step.get('col_tail'):
+        parts['col_tail'] = 4.0 * nd * rem * fl * 16.0
+    return sum(parts.values()), parts
+
+
+def pmc_chain_traffic():
+    """HBM bytes of one hinted stack from the latest committed PMC summary (`__chain__` entry written by
+    scripts/hbm_traffic.py: the dispatches between two `set_state` markers), or (None, None)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_pmc.json')),
+                   key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
+    if not files:
+        return None, None
+    for e in json.load(open(files[-1])):
+        if e.get('kernel') == '__chain__':
+            return (e['fetch_corrected_MB'] + e['write_size_MB']) * 1024 * 1024, os.path.basename(files[-1])
+    return None, None
 
 
 def pmc_traffic(kernel_class):
@@ -208,6 +249,55 @@ def cpu_baseline(state, kernels, K, ndays_sample):
     return rec, fields
 
 
+def cold_run_record(hip_lib, state, kernels, K, nd, device):
+    """What a single `Run.main`-style run sees: the headline steps run on a warm
+    solver whose previous run raised no flag (one 30-day window).  `first_run`: a fresh solver's first
+    chain -- plans, buffer allocation, kernel upload excluded, windows ramp 2, 4, 8, 16; `unhinted`: the
+    same ramp on warm buffers (PS_NO_WINDOW_HINT), median of 3; `hinted`: one-window runs of the same solver."""
+    s = hip_lib.HipSolve(state, [K, K], mode='fast', device=device, chain_only=True)
+    s.set_kernels(kernels)
+    s.sync()
+
+    def timed():
+        t0 = time.perf_counter()
+        s.set_state(state)
+        s.run_chain(0, nd, negval=1e-8, scale=1.0, renorm=True)
+        s.sync()
+        return time.perf_counter() - t0
+
+    first = timed()
+    s.set_option('PS_NO_WINDOW_HINT', 1)
+    unh = sorted(timed() for _ in range(3))[1]
+    s.set_option('PS_NO_WINDOW_HINT', 0)
+    timed()
+    hin = sorted(timed() for _ in range(3))[1]
+    s.close()
+    r = lambda t: {'ms': round(t * 1e3, 3), 'grid_days_per_s': round(nd / t, 1)}
+    return {'first_run': r(first), 'unhinted': r(unh), 'hinted': r(hin),
+            'note': 'first_run includes first-touch allocation of the solver\'s buffers; value/ms_per_step are hinted runs'}
+
+
+def api_get_solutions_record(state, kernels, K, nd):
+    """`CalcSol.get_solutions` at the headline size through the package's reference-shaped API
+    (CalcSol.py:140-201): solver construction, kernel upload from host COO, the chain, and the COO export of
+    every day the reference returns (CalcSol.py:198) -- everything the timed steps leave out."""
+    from parasitoids_amd import CalcSol, globalvars
+    old = globalvars.fft_mode
+    globalvars.fft_mode = 'fast'
+    try:
+        modelsol = [state]
+        days = list(range(nd + 1))
+        t0 = time.perf_counter()
+        CalcSol.get_solutions(modelsol, [None] + list(kernels), days, nd + 1, state.shape[0], np.array([K, K]))
+        dt = time.perf_counter() - t0
+    finally:
+        globalvars.fft_mode = old
+    nnz = sum(int(m.nnz) for m in modelsol[1:])
+    return {'seconds': round(dt, 3), 'grid_days_per_s': round(nd / dt, 1), 'days': nd, 'mode': 'fast',
+            'coo_entries_returned': nnz, 'coo_bytes_d2h': nnz * 16,
+            'note': 'includes HipSolve construction, H2D of the kernel triplets and the D2H COO export of all days'}
+
+
 def max_abs_vs(solver, fields):
     return float(max(np.abs(solver.dense(0, d) - f).max() for d, f in enumerate(fields)))
 
@@ -261,6 +351,24 @@ def main():
         per = [float(x.item()) for x in allt]
         return max(per), per
 
+    def rank_identities():
+        """every rank's device as the runtime names it, on rank 0: the driver can see that the N ranks
+        of an RCCL job sat on N different GPUs (VERDICT r3 #9)"""
+        ident = {'rank': rank, 'local_device': local, 'backend': backend, 'pid': os.getpid()}
+        if not args.rehearse:
+            try:
+                pr = torch.cuda.get_device_properties(local)
+                ident['name'] = pr.name
+                ident['uuid'] = str(getattr(pr, 'uuid', None))
+                ident['pci_bus_id'] = getattr(pr, 'pci_bus_id', None)
+            except Exception as e:
+                ident['error'] = str(e)
+        if world == 1:
+            return [ident]
+        allv = [None] * world
+        dist.all_gather_object(allv, ident)
+        return allv
+
     def gather_parity(v):
         """every rank's own device-vs-oracle figure on rank 0 (a rank on the wrong device, or with a
         different result, cannot hide behind rank 0's)"""
@@ -278,16 +386,19 @@ def main():
     if args.rehearse:
         dist.barrier() if world > 1 else None
         dt, per = gather_times(1.0 + 0.0 * rank)
+        idents = rank_identities()
         mg = None
         if world > 1:
             import bench_extras
-            mg = bench_extras.multi_gpu_record(rank, world, rehearse=True)      # configs 4 / 5 control flow, stand-in work
+            mg = bench_extras.multi_gpu_record(rank, world, rehearse=True,       # configs 4 / 5 control flow, stand-in work
+                                               fail_stage=os.environ.get('BENCH_FAIL_STAGE'))
             par = gather_parity(1e-19 * (rank + 1))
         if rank == 0:
             print(json.dumps({'metric': 'grid-days/sec on 4096^2 fp64 domain', 'value': None,
                               'unit': 'grid-days/s', 'n_gpus': dist.get_world_size() if world > 1 else 1,
                               'steps': args.steps, 'warmup': args.warmup, 'rehearsal': True,
                               'ranks_seen': len(per), 'backend': backend,
+                              'world_size': dist.get_world_size() if world > 1 else 1, 'ranks': idents,
                               'multi_gpu': mg, 'parity': {'per_rank_max_abs': par} if world > 1 else None}))
         if world > 1:
             dist.barrier()
@@ -346,8 +457,10 @@ def main():
     dt_own = time.perf_counter() - t0
     prof = solver.prof_read()
     prof_days = solver.prof_days()
+    prof_launches = solver.prof_launches()
     solver.prof_enable(False)
     dt, per_rank = gather_times(dt_own)
+    idents = rank_identities()
     rank_parity = None
     if world > 1 and not args.no_cpu_baseline:
         # every rank checks ITS stack against the oracle (2 day steps, ~5 s of one host core each)
@@ -416,6 +529,8 @@ def main():
                        'dom_len': N, 'ndays': nd, 'kshape': K, 'P': P, 'fft_len': solver.fft_len,
                        'kernels_direct': bool(solver.kernels_direct), 'full_column_pipeline': bool(solver.full_column)},
             'per_rank_grid_days_per_s': [round(args.steps * nd / t, 2) for t in per_rank],
+            'world_size': nranks, 'backend': backend if world > 1 else None, 'ranks': idents,
+            'distinct_devices': len(set((i.get('uuid'), i.get('pci_bus_id'), i.get('local_device')) for i in idents)),
             # SURVEY 8d's normative whole-chain figure: the unfused model's 96 P^2 per grid-day
             # times the measured rate.  A model rate, not a bandwidth measurement.
             'alg_bytes_per_grid_day': 96.0 * P * P,
@@ -449,6 +564,26 @@ def main():
                                                 if (traffic_src and pmc_traffic.provenance) else None)},
             'kernels': kern,
         }
+        # Whole-chain roofline: the compulsory bytes of the stack as launched / the
+        # measured step time, next to the PMC bytes of one stack.  SURVEY 8d's 96 P^2 model above
+        # (`alg_*`, `survey_model_*`) is superseded for this code: fusion keeps the state column in LDS
+        # for all 30 days and never writes kernel spectra, so that model counts bytes nobody moves.
+        per_step = {k: prof_launches.get(k, 0) / float(args.steps) for k in prof_launches}
+        cb, cparts = chain_compulsory_bytes(N, K, fl, nd, kernels, per_step, kern)
+        step_s = dt / args.steps
+        ctraffic, csrc = pmc_chain_traffic() if (R, K, nd) == (2048, 2049, 30) else (None, None)
+        out['roofline']['chain'] = {
+            'bytes_per_step': cb, 'achieved': round(cb / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(cb / step_s / 1e9 / HBM_PEAK_GBS, 4),
+            'bytes_by_class': {k: round(v) for k, v in cparts.items()},
+            'launches_per_step': {k: round(v, 2) for k, v in per_step.items() if v},
+            'traffic': ctraffic,
+            'traffic_frac': round(ctraffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if ctraffic else None,
+            'traffic_source': ('profiles/%s' % csrc) if csrc else None,
+            'hbm_roof_grid_days_per_s': round(nd / (cb / (HBM_PEAK_GBS * 1e9)), 1),
+            'note': 'compulsory bytes of the stack as launched (state in/out per chained pass, one intermediate '
+                    'and one N x N record per day, live kernel rows, staging, set_state); survey_model_* / alg_* '
+                    'are SURVEY 8d\'s unfused 96 P^2 model, superseded'}
         if dom.startswith('col_inv_a') and solver.full_column:
             # the full-column day pass is two length-L complex transforms and one product per column
             # and day: what its time is spent on (nominal 5 L log2 L flops per transform); the fp64
@@ -483,7 +618,17 @@ def main():
                 s2.close()
             par['ok'] = all(v < 1e-12 for k, v in par.items() if k.startswith('max_abs'))
             out['parity'] = par
+            # the same figures where a reader of only `roofline` / `config` finds them
+            out['roofline']['parity'] = dict(par)
+            out['config']['parity_max_abs'] = max(v for k, v in par.items() if k.startswith('max_abs'))
+            out['config']['parity_ok'] = par['ok']
             del ofields
+            if args.mode == 'fast' and not args.no_extras:
+                try:
+                    out['cold_first_run'] = cold_run_record(hip_lib, state, kernels, K, nd, local)
+                    out['api_get_solutions'] = api_get_solutions_record(state, kernels, K, nd)
+                except Exception as e:          # a sub-record must not cost the headline line
+                    out['cold_first_run'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if rank_parity is not None:
             out['parity'] = {'days': 2, 'tolerance': 1e-12, 'per_rank_max_abs': rank_parity,
                              'ok': all(v < 1e-12 for v in rank_parity)}

@@ -197,8 +197,48 @@ def bayes_case(rad_res, mode, samples, burn, device=None, seed=1000):
            'evaluation_fraction': round(ev / float(samples), 4),
            'failed_evaluations': res['failed_evaluations'],
            'logp_first_last': [round(float(res['logp'][0]), 3), round(float(res['logp'][-1]), 3)]}
+    import hashlib
+    rec['trace_sha256'] = hashlib.sha256(np.ascontiguousarray(res['trace']).tobytes()).hexdigest()
     pm.close()
     return rec, days
+
+
+def bayes_multi_case(rad_res, mode, k, samples, burn, device=None, seed0=1000, single_sha=None):
+    """k independent chains in ONE process on one GPU (mcmc.run_parallel: a host thread, a PopModel and
+    its streams per chain; seeds seed0 .. seed0 + k - 1).  Aggregate samples and evaluations per hour over
+    the wall time of the timed window; `chain0_sha256` is the digest of chain 0's trace, to be compared
+    with the single-chain run of the same seed (`bitwise_equal_to_single_chain`)."""
+    import hashlib
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd import mcmc
+    from parasitoids_amd.Data_Import import LocInfo
+    from parasitoids_amd.pop_model import PopModel
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    li = LocInfo('kalbar', (-27.947131, 152.584171), (10000.0, rad_res))
+    pms, chains = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        for c in range(k):
+            pm = PopModel(wd, days, domain_info=(10000.0, rad_res), r_number=130000, mode=mode, device=device)
+            pms.append(pm)
+            chains.append(mcmc.Sampler(pm, li, (10000.0 / rad_res) ** 2, seed=seed0 + c))
+        mcmc.run_parallel(chains, burn)
+        res, dt = mcmc.run_parallel(chains, samples)
+    ev = sum(r['evaluations_this_run'] for r in res)
+    sha = hashlib.sha256(np.ascontiguousarray(res[0]['trace']).tobytes()).hexdigest()
+    rec = {'chains_per_gpu': k, 'value': round(3600.0 * k * samples / dt, 1), 'unit': 'samples/hour (sum over the chains)',
+           'evaluations_per_hour': round(3600.0 * ev / dt, 1), 'timed_window_s': round(dt, 3),
+           'ms_per_sample_aggregate': round(1e3 * dt / (k * samples), 3),
+           'evaluation_fraction': round(ev / float(k * samples), 4),
+           'per_chain_samples_per_hour': [round(r['samples_per_hour'], 1) for r in res],
+           'per_chain_acceptance': [round(r['acceptance'], 3) for r in res],
+           'seeds': [seed0 + c for c in range(k)], 'samples_per_chain': samples, 'burn': burn,
+           'mode': pms[0].solver.mode, 'fft_len': pms[0].solver.fft_len, 'chain0_sha256': sha}
+    if single_sha is not None:
+        rec['bitwise_equal_to_single_chain'] = bool(sha == single_sha)
+    for pm in pms:
+        pm.close()
+    return rec
 
 
 def bayes_record(device=None, samples=600, burn=50, cpu=True):
@@ -226,6 +266,21 @@ def bayes_record(device=None, samples=600, burn=50, cpu=True):
                 out[key], days = bayes_case(R, mode, samples, burn, device)
             except Exception as e:
                 out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+    # the same chain next to k - 1 others on the one GPU (seeds 1000 .. 1000 + k - 1; chain 0 = the run above)
+    for k in (2, 4):
+        key = 'r400_auto_x%d' % k
+        try:
+            out[key] = bayes_multi_case(400, 'auto', k, samples, burn, device,
+                                        single_sha=out.get('r400_auto', {}).get('trace_sha256'))
+        except Exception as e:
+            out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+    best = max((out[k] for k in ('r400_auto', 'r400_auto_x2', 'r400_auto_x4') if 'evaluations_per_hour' in out.get(k, {})),
+               key=lambda r: r['evaluations_per_hour'], default=None)
+    if best is not None:
+        out['per_gpu'] = {'evaluations_per_hour': best['evaluations_per_hour'], 'samples_per_hour': best['value'],
+                          'chains_per_gpu': best.get('chains_per_gpu', 1),
+                          'note': 'most evaluations/hour one GPU delivers: independent chains side by side in one '
+                                  'process, each bit-identical to running alone'}
     if 'value' in out.get('r400_auto', {}):
         out['value'] = out['r400_auto']['value']            # exact-torus results at the reference's grid
     if 'evaluations_per_hour' in out.get('r400_auto', {}):
@@ -331,7 +386,7 @@ def _ensemble_runner(device, rad_res, ndays):
 
 
 def multi_gpu_record(rank, world, device=None, rehearse=False, members_per_rank=4, rad_res=1024, ndays=30,
-                     chain_samples=300, chain_burn=30):
+                     chain_samples=300, chain_burn=30, fail_stage=None):
     """What the N-rank job is for besides replica stacks: BASELINE config 5 -- ensemble
     members round-robin over the ranks (`parallel.run_members`, results gathered on rank 0) -- and
     config 4 -- one independent MCMC chain per rank, chain c seeded 1000 + c.  No data-path
@@ -346,23 +401,42 @@ def multi_gpu_record(rank, world, device=None, rehearse=False, members_per_rank=
             dist.barrier()
 
     out = {'n_gpus': world}
+    # Every rank takes part in EVERY collective below whatever happens to its own work: a
+    # stage that fails on one rank turns into an error object that travels through the same gathers,
+    # instead of that rank skipping ahead to the final barrier while the others wait in this one.
+    errors = []
+
+    def guarded(stage, fn, fallback):
+        try:
+            return fn()
+        except Exception as e:
+            errors.append('%s on rank %d: %s: %s' % (stage, rank, type(e).__name__, e))
+            return fallback
+
     # ---- config 5
     members = ensemble_members(members_per_rank * world)
+    model = None
     if rehearse:
-        model = None
         run = lambda mem: {'total': 1.0, 'nnz_last': int(1000 * mem['lam'])}
     else:
-        run, model = _ensemble_runner(device, rad_res, ndays)
-        run(members[rank])                      # warm-up: solvers, plans, buffers
+        run, model = guarded('ensemble setup', lambda: _ensemble_runner(device, rad_res, ndays), (None, None))
+        if run is not None:
+            guarded('ensemble warm-up', lambda: run(members[rank]), None)   # solvers, plans, buffers
+    if fail_stage == 'ensemble' and rank == world - 1:
+        run = None                              # test hook: this rank's members fail
+    run_safe = lambda mem: guarded('ensemble member', lambda: run(mem), {'error': True})
     barrier()
     t0 = time.perf_counter()
-    res = parallel.run_members(members, run)
+    res = parallel.run_members(members, run_safe)
     dt_own = time.perf_counter() - t0           # this rank's members (rank 0: + the gather)
     own = len(members[rank::world])
-    times = parallel.gather_objects((rank, own, dt_own))
+    times = parallel.gather_objects((rank, own, dt_own, list(errors)))
     if model is not None:
-        model.close()
-    if rank == 0:
+        guarded('ensemble close', model.close, None)
+    if rank == 0 and any(e for _, _, _, e in times):
+        out['ensemble'] = {'error': [m for _, _, _, e in times for m in e]}
+    elif rank == 0:
+        times = [t[:3] for t in times]
         dt = max(t for _, _, t in times)
         out['ensemble'] = {'workload': 'BASELINE config 5: %d members (lambda, sigma, mu_r from the priors) x %d^2 grid x '
                                        '%d Carnarvon days, probability model, member i on rank i mod %d'
@@ -375,15 +449,21 @@ def multi_gpu_record(rank, world, device=None, rehearse=False, members_per_rank=
                            'all_members_conserve_mass': bool(all(abs(r['total'] - 1.0) < 1e-6 or r['total'] < 1.0 + 1e-9 for r in res))}
     # ---- config 4
     seed = 1000 + rank
+    del errors[:]
     if rehearse:
         rec = {'value': 1.0e6 + seed, 'evaluations_per_hour': 0.8e6, 'evaluation_fraction': 0.8, 'acceptance': 0.4,
                'timed_window_s': 1.0, 'samples': chain_samples}
+        if fail_stage == 'bayes' and rank == world - 1:
+            rec = guarded('chain', lambda: 1 / 0, None)
     else:
-        rec, _ = bayes_case(400, 'auto', chain_samples, chain_burn, device, seed=seed)
+        rec = guarded('chain', lambda: bayes_case(400, 'auto', chain_samples, chain_burn, device, seed=seed)[0], None)
     barrier()
-    chains = parallel.gather_objects((rank, seed, rec))
+    chains = parallel.gather_objects((rank, seed, rec, list(errors)))
+    if rank == 0 and any(r is None for _, _, r, _ in chains):
+        out['bayes'] = {'error': [m for _, _, _, e in chains for m in e]}
+        return out
     if rank == 0:
-        chains = sorted(chains)
+        chains = sorted(c[:3] for c in chains)
         out['bayes'] = {'workload': 'BASELINE config 4: %d independent chains, one per rank, chain c seeded 1000 + c, '
                                     'Kalbar, R = 400 (the reference\'s grid), exact-torus results' % world,
                         'value': round(sum(r['value'] for _, _, r in chains), 1), 'unit': 'samples/hour (sum over chains)',

@@ -66,6 +66,7 @@
   X("PS_KT_SPLIT", kt_split, -1, INT, R)                                                            \
   X("PS_NO_LAZY_KT", no_lazy_kt, 0, FLAG, R)                                                        \
   X("PS_NO_WIDE", no_wide, 0, FLAG, R)                                                              \
+  X("PS_NO_ROUTE_HISTORY", no_route_history, 0, FLAG, R)                                            \
   X("PS_WIDE_MIN_N", wide_min_n, 1500, INT, R)                                                      \
   X("PS_AUTO_WINDOW", auto_window, 4, INT, R)                                                       \
   /* prob_mass (ps_model handles) */                                                                \

@@ -254,6 +254,10 @@ struct ps_solver {
   bool borrowed = false;       // helper: stream and chain records belong to the parent
   bool child_kernels = false, wide_kernels = false;   // the helper holds the current day kernels
   std::vector<signed char> owner;   // per chain day of the last run: 0 this solver, 1 wide, 2 child
+  // the route of the last COMPLETED hand-over (days [route_first, route_end)): the next run over the same
+  // days sizes its helper windows by it instead of feeling its way four days at a time (auto_handover)
+  std::vector<signed char> route_hist;
+  int route_first = -1, route_end = -1;
   int auto_first_regime = 2;        // helper the last hand-over started with (1 wide, 2 child)
   int auto_first = -1;         // first day of the last chain_run that ran in the child (-1: none)
   int auto_hint = -1;          // the same, relative to `first`, remembered for the next run
@@ -1186,6 +1190,7 @@ extern "C" int ps_solver_retarget(ps_solver* s, int max_shape) {
     }
     s->child_kernels = false;
     s->wide_kernels = false;
+    s->route_first = s->route_end = -1;   // another torus, another route
     s->M = m;
     s->Pref = s->N + m;
     s->have_state = false;
@@ -1607,15 +1612,35 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   const int wide_min_n = s->cfg.wide_min_n;
   const bool no_wide = s->cfg.no_wide || s->N < wide_min_n;   // fold child for everything
   const int kWin = std::min(64, std::max(1, s->cfg.auto_window));
+  // Route history: sampler chains and repeated runs take much the same route every time.  With the
+  // previous run's route at hand a helper gets its whole stretch of days in ONE ps_chain_run (no host
+  // round trip every four days, no days enqueued behind a hand-over and thrown away), the wide helper
+  // is not even tried on a day that was dusty last time, and the child keeps going over a flagged day
+  // when the day after it was dusty again (it is exact on any day; only speed says to leave it).  Every
+  // window is still checked against what the days really did: a wrong history costs time, never
+  // correctness.  PS_NO_ROUTE_HISTORY=1: A/B knob.
+  std::vector<signed char> hist;
+  if (!s->cfg.no_route_history && s->route_first == first && s->route_end == end) hist = s->route_hist;
   if ((int)s->owner.size() < end) s->owner.resize(end, 0);
   for (int d = first; d < f; ++d) s->owner[d] = 0;
   enum { WIDE = 1, CHILD = 2 };
+  auto hist_owner = [&](int q) { return q >= 0 && q < (int)hist.size() && q < end ? (int)hist[q] : -1; };
+  auto stretch = [&](int q, int who) {   // days from q on that belonged to `who` last time (0: no history)
+    int e = q;
+    while (e < end && e - q < 64 && hist_owner(e) == who) ++e;
+    return e - q;
+  };
   int regime = (no_wide || !(m_front > 1e-8)) ? CHILD : WIDE;
   s->auto_first_regime = regime;
   bool wide_live = false, child_live = false;   // the helper's state continues the chain at day d
   int d = f;
   while (d < end) {
     const double* prev = auto_prev_field(s, first, d);
+    if (regime == WIDE && hist_owner(d) == CHILD) {   // dusty last time: do not try the wide torus on it
+      regime = CHILD;
+      wide_live = false;
+      continue;
+    }
     if (regime == WIDE) {
       PS_TRY(auto_attach(s, &s->wide, PS_MODE_FAST, 4 * s->M + 1, &s->wide_kernels, end));
       ps_solver* c = s->wide;
@@ -1629,7 +1654,8 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
         wide_live = true;
         child_live = false;
       }
-      const int w = std::min(kWin, end - d);
+      const int hw = stretch(d, WIDE);
+      const int w = std::min(hw > 0 ? hw : kWin, end - d);
       PS_TRY(auto_alias_records(s, c, d, d + w));
       PS_TRY(ps_chain_run(c, d, w, negval, stat_scale, renorm));
       double m[64];
@@ -1657,7 +1683,8 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
         child_live = true;
         wide_live = false;
       }
-      const int w = no_wide ? end - d : std::min(kWin, end - d);
+      const int hc = stretch(d, CHILD);
+      const int w = no_wide ? end - d : std::min(hc > 0 ? hc : kWin, end - d);
       PS_TRY(auto_alias_records(s, c, d, d + w));
       PS_TRY(ps_chain_run(c, d, w, negval, stat_scale, renorm));
       int g = -1;
@@ -1665,7 +1692,8 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
         double m[64];
         PS_TRY(auto_read_padmax(s, c, d, std::min(w, 64), m));
         for (int i = 0; i < w && g < 0; ++i)
-          if (m[i] > 1e-8) g = d + i;                             // flagged: truncated, domain-supported again
+          if (m[i] > 1e-8 && hist_owner(d + i + 1) != CHILD) g = d + i;   // flagged: truncated, domain-supported again
+                                                                          // (and not dusty again the day after, last time)
       }
       const int keep = g < 0 ? d + w : g + 1;
       for (int q = d; q < keep; ++q) s->owner[q] = CHILD;
@@ -1678,6 +1706,9 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   }
   s->auto_first = f;
   s->auto_hint = f - first;
+  s->route_hist.assign(s->owner.begin(), s->owner.begin() + end);
+  s->route_first = first;
+  s->route_end = end;
   s->have_state = false;   // the front's spectrum is void now: per-call API needs a new state
   return PS_OK;
 }

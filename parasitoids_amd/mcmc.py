@@ -41,8 +41,13 @@ from . import _lib
 
 # library return codes that mean "the model rejects these parameters" (ParasitoidModel.py:528-537,
 # :568-599 raise AssertionError for them; a kernel that outgrows the pad is a shape error)
+# PS_ERR_UNSUPPORTED: the proposal's kernel extent asks for a torus this solver mode cannot plan
+# (mode='exact' and a pad with a prime factor > 1024, or any mode beyond the size limit) -- a property
+# of the PARAMETERS in that mode, so the proposal is rejected and counted (`failed_evaluations`), the
+# chain goes on; 'auto' / 'fast' never produce it below the size limit.  Device errors (PS_ERR_HIP,
+# PS_ERR_OOM, PS_ERR_STATE) are not in this list: they stop the run with their cause.
 _PARAMETER_ERRORS = (_lib.PS_ERR_HPROB_BOUNDS, _lib.PS_ERR_PMF_NEGATIVE, _lib.PS_ERR_FLIGHT_PROB,
-                     _lib.PS_ERR_BAD_SHAPE, _lib.PS_ERR_EMPTY)
+                     _lib.PS_ERR_BAD_SHAPE, _lib.PS_ERR_EMPTY, _lib.PS_ERR_UNSUPPORTED)
 
 NEG_INF = float('-inf')
 
@@ -629,6 +634,37 @@ class Sampler():
         self.expected = self._evaluate(self.theta)
         self._refresh()
         return f['trace'], f['logp']
+
+
+def run_parallel(samplers, nsamples):
+    """Run several independent chains of ONE process side by side, one host thread each (BASELINE
+    config 4 keeps one chain per GPU; this fills a GPU that a single R = 400 chain leaves mostly
+    idle).  Every sampler owns its PopModel -- its own model / solver handles and HIP streams
+    (include/parasitoid_hip.h: handles are independent) -- and its own random stream, the library
+    calls release the GIL, so the chains' launches interleave on the device and one chain's host work
+    (proposal, likelihood) hides behind the others' kernels.  A chain's trace does not depend on what
+    runs next to it: bit-identical to `sampler.run(nsamples)` on its own.
+    -> (list of run() results in sampler order, wall seconds)"""
+    import threading
+    out = [None] * len(samplers)
+    errs = []
+
+    def work(i):
+        try:
+            out[i] = samplers[i].run(nsamples)
+        except BaseException as e:      # re-raised in the caller's thread
+            errs.append((i, e))
+
+    threads = [threading.Thread(target=work, args=(i,), name='chain-%d' % i) for i in range(len(samplers))]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0][1]
+    return out, dt
 
 
 class Metropolis(Sampler):

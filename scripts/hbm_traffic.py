@@ -29,6 +29,35 @@ def read(d, counter):
     return {k: [v[i] for i in sorted(v)] for k, v in acc.items()}   # in dispatch order
 
 
+def read_ordered(d, counter):
+    """[(dispatch id, kernel, value KB)] of the whole pass, in dispatch order"""
+    acc = {}
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row['Counter_Name'] != counter:
+                    continue
+                did = int(row['Dispatch_Id'])
+                name = row['Kernel_Name'].split('(')[0]
+                acc[did] = (name, acc.get(did, (name, 0.0))[1] + float(row['Counter_Value']))
+    return [(i, acc[i][0], acc[i][1]) for i in sorted(acc)]
+
+
+def chain_segments(d, counter, marker='k_set_int2'):
+    """KB per stack: the dispatches between two `set_state` markers (ps_solver_set_state_coo launches
+    k_set_int2 exactly once) -- everything one `set_state` + `run_chain` step of bench.py enqueues.  The
+    first segment (solver construction) and the last (followed by the read-back) are left out."""
+    segs, cur = [], None
+    for _, name, v in read_ordered(d, counter):
+        if name == marker:
+            if cur is not None:
+                segs.append(cur)
+            cur = 0.0
+        elif cur is not None:
+            cur += v
+    return segs[1:] if len(segs) > 2 else segs       # [construction | stack ...] ; the open last one is never appended
+
+
 def clusters(vals):
     """indices of `vals` grouped into clusters of similar size (neighbours within 25 %), ascending"""
     order = sorted(range(len(vals)), key=lambda i: vals[i])
@@ -70,6 +99,16 @@ def main(fd, wd, out, prov=None):
                  'write_size_MB': (sum(wv[i] for i in idx) / n / 1024.0) if wv is not None and len(wv) == len(fv)
                  else ((sum(wv) / len(wv) / 1024.0) if wv else None)}
             res.append(e)
+    # one stack = one step of bench.py: whole-chain traffic next to bench.py's `roofline.chain`
+    fs, ws = chain_segments(fd, 'FETCH_SIZE'), chain_segments(wd, 'WRITE_SIZE')
+    if fs and ws:
+        # the hinted stacks (one 30-day window) are the steps bench.py times: the last segments; median
+        k = max(1, min(len(fs), len(ws)) - 1)
+        med = lambda v: sorted(v)[len(v) // 2]
+        res.append({'kernel': '__chain__', 'stacks': k, 'fetch_size_MB': med(fs[-k:]) / 1024.0,
+                    'fetch_corrected_MB': 2.0 * med(fs[-k:]) / 1024.0, 'write_size_MB': med(ws[-k:]) / 1024.0,
+                    'per_stack_fetch_corrected_MB': [round(2.0 * x / 1024.0, 1) for x in fs],
+                    'per_stack_write_MB': [round(x / 1024.0, 1) for x in ws]})
     if prov:
         res.append(provenance(prov))     # which build these counters belong to (bench.py echoes it)
     json.dump(res, open(out, 'w'), indent=1)

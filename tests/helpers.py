@@ -41,3 +41,21 @@ def assert_summary(g, prefix, M, pos, rtol=1e-12, atol=1e-12, nnz_slack=0):
     assert np.isclose(wsum(M), float(g[prefix + '_wsum']), rtol=max(rtol, 1e-11), atol=atol)
     samp = np.asarray(C[pos[:, 0], pos[:, 1]]).ravel()
     np.testing.assert_allclose(samp, g[prefix + '_samp'], rtol=rtol, atol=atol)
+
+
+def check_digest(g, name, got, tol=5e-15):
+    """device COO kernel against a g5b fixture: shape, nnz, the (row, col) pattern in entry order
+    (SHA-256), every sampled entry, the sum"""
+    import hashlib
+    got = got.tocoo()
+    assert tuple(got.shape) == tuple(g[name + '_shape']), (name, got.shape)
+    assert got.nnz == int(g[name + '_nnz']), (name, got.nnz, int(g[name + '_nnz']))
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(got.row.astype(np.int32)).tobytes())
+    h.update(np.ascontiguousarray(got.col.astype(np.int32)).tobytes())
+    assert h.digest() == g[name + '_pattern_sha256'].tobytes(), name + ': COO pattern differs'
+    idx = g[name + '_samp_idx']
+    assert np.array_equal(got.row[idx], g[name + '_samp_row']) and np.array_equal(got.col[idx], g[name + '_samp_col'])
+    np.testing.assert_allclose(got.data[idx], g[name + '_samp_val'], rtol=0, atol=tol, err_msg=name)
+    assert abs(got.data.sum() - float(g[name + '_sum'])) < 1e-12
+    assert int(np.argmax(got.data)) == int(g[name + '_argmax'])

@@ -51,3 +51,16 @@ def test_bench_bayes_gpus2_launches_two_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     assert json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_a_failing_rank_does_not_hang_the_multi_gpu_record():
+    """every rank takes part in every collective of multi_gpu_record; a stage that fails on
+    one rank arrives on rank 0 as an error record instead of leaving the others in a barrier."""
+    for stage, other in (('ensemble', 'bayes'), ('bayes', 'ensemble')):
+        p = _run('bench.py', '--gpus', '2', '--rehearse', env={'BENCH_FAIL_STAGE': stage})
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+        mg = d['multi_gpu']
+        assert 'error' in mg[stage] and any('rank 1' in m for m in mg[stage]['error']), mg[stage]
+        assert 'error' not in mg[other]
+        assert d['world_size'] == 2 and [r['rank'] for r in d['ranks']] == [0, 1]

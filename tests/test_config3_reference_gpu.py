@@ -1,0 +1,101 @@
+"""BASELINE config 3 on real wind at FULL size against the reference itself (G6b).
+
+`tests/golden/make_golden.py g6b` ran the reference's `prob_mass` for 30 Carnarvon days at R = 2048
+(N = 4097) and its `get_solutions` (CalcSol.py:140-201, CPU branch) at rad_dist 10 km (C3a: 19 of
+29 days raise the boundary flag) and 40 km (C3b: none does), and stored digests: per day kernel and
+per solution day shape, nnz, sum, SHA-256 of the (row, col) pattern and ~400 evenly spaced entries;
+per chain day the flag and 1000 samples of the raw field.  Here the device builds the same kernels
+and runs the same chains:
+
+  * kernels: identical pattern, sampled values to 5e-15 (the G5b bar, now for all 2 x 30 days);
+  * `auto` mode (exact reference-torus semantics): flags identical, raw fields to 1e-12, thresholded
+    and renormalised solutions (CalcSol.py:126-135) to 1e-12 with the same pattern -- entries within
+    1e-12 of the 1e-8 cut may differ in membership (SURVEY 8d parity gate) and are counted;
+  * `fast` mode: flags identical, raw fields to 5e-8.
+"""
+import hashlib
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import HP, DP, DLP, MU_R, NPER, check_digest
+
+pytestmark = pytest.mark.gpu
+
+R, ND = 2048, 30
+N = 2 * R + 1
+
+
+@pytest.fixture(scope='module')
+def carnarvon():
+    from parasitoids_amd import ParasitoidModel as PM
+    return PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+
+
+def _pattern_sha(M):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(M.row.astype(np.int32)).tobytes())
+    h.update(np.ascontiguousarray(M.col.astype(np.int32)).tobytes())
+    return h.digest()
+
+
+@pytest.mark.parametrize('tag,rad_dist', [('c3b', 40000.0), ('c3a', 10000.0)])
+def test_config3_full_size_against_the_reference(tag, rad_dist, golden, carnarvon):
+    from parasitoids_amd.pop_model import PopModel
+    from parasitoids_amd import _lib as L
+    g = golden('g6b_config3_full')
+    if tag + '_flags' not in g.files:
+        pytest.skip('fixture holds no %s variant' % tag)
+    wd, days = carnarvon
+    assert [int(d) for d in g['days']] == [int(d) for d in days[:ND]]
+    pos = g['pos']
+    ref_flags = [bool(f) for f in g[tag + '_flags']]
+    assert sum(ref_flags) == (19 if tag == 'c3a' else 0)
+    for mode, raw_tol in (('auto', 1e-12), ('fast', 5e-8)):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            pm = PopModel(wd, days, domain_info=(rad_dist, R), mode=mode, prob_model=True)
+            pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=ND)
+            if mode == 'auto':
+                # the day kernels themselves, all 30 of them, against the reference's
+                assert int(pm.model.last['kshape'].max()) == int(g[tag + '_max_shape'].max())
+                for i in range(ND):
+                    check_digest(g, '%s_pmf%d' % (tag, i), pm.model.fetch(i))
+                pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=ND)     # the hinted / history-guided run
+        s = pm.solver
+        st = pm.stats
+        assert [bool(x.flag) for x in st] == ref_flags, mode
+        worst = 0.0
+        for d in range(ND - 1):
+            raw = s.dense(L.REC_CHAIN, d)
+            got = raw[pos[:, 0], pos[:, 1]]
+            err = float(np.abs(got - g[tag + '_rawsamp'][d]).max())
+            worst = max(worst, err)
+            assert err <= raw_tol, (mode, d, err)
+            assert abs(float(raw.sum()) - float(g[tag + '_rawsum'][d])) <= 4e3 * raw_tol   # ~1e7 cells, errors do not align
+            if mode != 'auto':
+                continue
+            # thresholded + renormalised solution of day d + 1
+            name = '%s_sol%d' % (tag, d + 1)
+            sol = s.chain_solution(d, st[d]).tocoo()
+            near_cut = int(np.count_nonzero(np.abs(raw - 1e-8) < 2e-12))
+            ref_nnz = int(g[name + '_nnz'])
+            assert abs(sol.nnz - ref_nnz) <= near_cut, (d, sol.nnz, ref_nnz, near_cut)
+            assert abs(float(sol.data.sum()) - 1.0) < 1e-11 and abs(float(g[name + '_sum']) - 1.0) < 1e-11
+            if sol.nnz == ref_nnz and _pattern_sha(sol) == g[name + '_pattern_sha256'].tobytes():
+                idx = g[name + '_samp_idx']
+                assert np.array_equal(sol.row[idx], g[name + '_samp_row'])
+                assert np.array_equal(sol.col[idx], g[name + '_samp_col'])
+                np.testing.assert_allclose(sol.data[idx], g[name + '_samp_val'], rtol=0, atol=1e-12)
+            else:
+                assert near_cut > 0, (d, 'pattern differs with no entry near the cut')
+                C = sol.tocsr()
+                v = np.asarray(C[g[name + '_samp_row'], g[name + '_samp_col']]).ravel()
+                bad = np.abs(v - g[name + '_samp_val']) > 1e-12
+                assert np.count_nonzero(bad) <= near_cut
+            v = np.asarray(sol.tocsr()[pos[:, 0], pos[:, 1]]).ravel()
+            bad = np.abs(v - g['%s_solsamp%d' % (tag, d + 1)]) > 1e-12
+            assert np.count_nonzero(bad) <= near_cut, (d, int(np.count_nonzero(bad)))
+        print('%s %s: max |device - reference| over %d sampled raw values per day: %.2e' % (tag, mode, len(pos), worst))
+        pm.close()

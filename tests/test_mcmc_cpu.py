@@ -278,3 +278,43 @@ def test_likelihood_statistics_equal_the_array_form(golden):
         nuis, sp = np.array([1.0, 0.5, 0.01]), np.full(nf, 0.1)
         assert mcmc.loglik_parts(exp2, li, nuis, sp)[0] == mcmc.NEG_INF
         assert mcmc.loglik_parts_stats(mcmc.lik_stats(exp2, li), nuis, sp)[0] == mcmc.NEG_INF
+
+
+def test_parallel_chains_equal_the_same_chains_run_alone(golden):
+    """mcmc.run_parallel: k chains in k host threads; every chain owns its state and random stream, so
+    its trace is the one it produces alone."""
+    g = golden('g9_bayes_funcs')
+    alone = [_fake_sampler(g, 100 + c, delay=20, interval=10, tune_interval=15).run(40) for c in range(3)]
+    chains = [_fake_sampler(g, 100 + c, delay=20, interval=10, tune_interval=15) for c in range(3)]
+    res, dt = mcmc.run_parallel(chains, 40)
+    assert dt > 0 and len(res) == 3
+    for a, b in zip(alone, res):
+        assert np.array_equal(a['trace'], b['trace']) and np.array_equal(a['logp'], b['logp'])
+    assert not np.array_equal(res[0]['trace'], res[1]['trace'])      # different seeds, different chains
+
+
+def test_unplannable_torus_rejects_the_proposal_device_errors_stop_the_chain(golden, monkeypatch):
+    """PS_ERR_UNSUPPORTED from a shape-dependent solver rebuild (mode='exact' and a pad with a
+    prime factor > 1024) is a property of the proposed parameters: rejected and counted.  A device error
+    is not: it stops the run."""
+    from parasitoids_amd import _lib
+    g = golden('g9_bayes_funcs')
+    li, cell_area = g9_locinfo(g)
+    base = ([g['rel0'], g['rel1']], [g['sen0'], g['sen1']], g['grid'])
+    monkeypatch.setattr(mcmc, 'expected_observations', lambda pm, li: base)
+    calls = {'n': 0, 'code': _lib.PS_ERR_UNSUPPORTED}
+
+    class FakeModel():
+        def evaluate(self, *a, **k):
+            calls['n'] += 1
+            if calls['n'] % 2 == 0:
+                raise _lib.HipError(calls['code'], 'cannot plan a length-1031 FFT')
+
+    s = mcmc.Sampler(FakeModel(), li, cell_area, seed=3)
+    r = s.run(12)
+    assert r['failed_evaluations'] >= 1 and r['failed_evaluations'] == s.n_failed
+    assert np.all(np.isfinite(r['logp']))
+    calls['code'] = _lib.PS_ERR_HIP
+    import pytest
+    with pytest.raises(_lib.HipError):
+        s.run(12)

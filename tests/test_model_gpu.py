@@ -10,7 +10,7 @@ import pytest
 from scipy import sparse
 
 from oracle import model as OM
-from helpers import HP, DP, DLP, MU_R, NPER, HP_T, DP_T, coo_from
+from helpers import HP, DP, DLP, MU_R, NPER, HP_T, DP_T, coo_from, check_digest
 
 pytestmark = pytest.mark.gpu
 
@@ -189,24 +189,6 @@ def test_prob_mass_random_parameters_against_oracle(PM, kalbar, carnarvon):
         assert abs(got.sum() - 1.0) < 1e-12
 
 
-def _check_digest(g, name, got, tol=VAL_ATOL):
-    """device COO kernel against a g5b fixture: shape, nnz, the (row, col) pattern in entry order
-    (SHA-256), every sampled entry, the sum"""
-    import hashlib
-    got = got.tocoo()
-    assert tuple(got.shape) == tuple(g[name + '_shape']), (name, got.shape)
-    assert got.nnz == int(g[name + '_nnz']), (name, got.nnz, int(g[name + '_nnz']))
-    h = hashlib.sha256()
-    h.update(np.ascontiguousarray(got.row.astype(np.int32)).tobytes())
-    h.update(np.ascontiguousarray(got.col.astype(np.int32)).tobytes())
-    assert h.digest() == g[name + '_pattern_sha256'].tobytes(), name + ': COO pattern differs'
-    idx = g[name + '_samp_idx']
-    assert np.array_equal(got.row[idx], g[name + '_samp_row']) and np.array_equal(got.col[idx], g[name + '_samp_col'])
-    np.testing.assert_allclose(got.data[idx], g[name + '_samp_val'], rtol=0, atol=tol, err_msg=name)
-    assert abs(got.data.sum() - float(g[name + '_sum'])) < 1e-12
-    assert int(np.argmax(got.data)) == int(g[name + '_argmax'])
-
-
 def test_prob_mass_large_grids_against_reference(PM, golden, kalbar, carnarvon):
     '''G5b: the REFERENCE's prob_mass at the grid sizes of BASELINE configs 2-5 -- Kalbar R = 512
     (stamp 59^2), a prior-drawn ensemble member (config 5, member 0) on Carnarvon at R = 1024
@@ -219,10 +201,10 @@ def test_prob_mass_large_grids_against_reference(PM, golden, kalbar, carnarvon):
     lam, sx, sy, mu = (float(v) for v in g['member0'])
     with warnings.catch_warnings():
         warnings.simplefilter('ignore', RuntimeWarning)
-        _check_digest(g, 'kal512', PM.prob_mass(days[0], wd, HP, DP, DLP, MU_R, NPER, 10000.0, 512))
-        _check_digest(g, 'car1024_member0',
+        check_digest(g, 'kal512', PM.prob_mass(days[0], wd, HP, DP, DLP, MU_R, NPER, 10000.0, 512))
+        check_digest(g, 'car1024_member0',
                       PM.prob_mass(dc[3], wc, (lam,) + tuple(HP[1:]), (sx, sy, 0.253), DLP, mu, NPER, 10000.0, 1024))
-        _check_digest(g, 'car2048_late', PM.prob_mass(dc[0], wc, HP, DP, DLP, MU_R, NPER, 10000.0, 2048, 0.93))
+        check_digest(g, 'car2048_late', PM.prob_mass(dc[0], wc, HP, DP, DLP, MU_R, NPER, 10000.0, 2048, 0.93))
 
 
 def test_prob_mass_pair_list_overflow_is_redone(PM, kalbar, monkeypatch):

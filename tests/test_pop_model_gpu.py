@@ -70,3 +70,35 @@ def test_pop_model_fast_mode_reuses_solvers_and_matches_exact():
         assert np.abs(a - b).max() <= 5e-8 * 130000
     assert len(fast._solvers) <= 2 and len(sizes) <= 2     # kernel shapes moved, solvers did not
     fast.close(); exact.close()
+
+
+def test_chains_side_by_side_on_one_gpu_are_bitwise_the_chains_alone():
+    '''k chains in one process (mcmc.run_parallel: a host thread, a PopModel with its own
+    model / solver handles and streams per chain) fill the card a single R = 400-class chain leaves idle.
+    What runs next to a chain must not change it: traces bit-identical to the same seeds run one at a time.'''
+    import warnings
+    from parasitoids_amd import ParasitoidModel as PM
+    from parasitoids_amd import mcmc
+    from parasitoids_amd.Data_Import import LocInfo
+    from parasitoids_amd.pop_model import PopModel
+    warnings.simplefilter('ignore', RuntimeWarning)
+    R = 200
+    wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+    li = LocInfo('kalbar', (-27.947131, 152.584171), (10000.0, R))
+
+    def chain(seed):
+        pm = PopModel(wd, days, domain_info=(10000.0, R), r_number=130000, mode='auto')
+        return pm, mcmc.Sampler(pm, li, (10000.0 / R) ** 2, seed=seed)
+
+    alone = []
+    for c in range(3):
+        pm, s = chain(1000 + c)
+        alone.append(s.run(25))
+        pm.close()
+    pairs = [chain(1000 + c) for c in range(3)]
+    res, dt = mcmc.run_parallel([s for _, s in pairs], 25)
+    for pm, _ in pairs:
+        pm.close()
+    for a, b in zip(alone, res):
+        assert np.array_equal(a['trace'], b['trace']) and np.array_equal(a['logp'], b['logp'])
+        assert b['evaluations_this_run'] == a['evaluations_this_run'] > 0
