@@ -636,6 +636,7 @@ def main():
             solver.close()
             import bench_extras
             for key, fn in (('real_wind', bench_extras.real_wind_record),
+                            ('release', lambda device=None: bench_extras.release_record()),
                             ('bayes', bench_extras.bayes_record)):
                 try:
                     out[key] = fn(device=local)

@@ -267,14 +267,14 @@ def bayes_record(device=None, samples=600, burn=50, cpu=True):
             except Exception as e:
                 out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
     # the same chain next to k - 1 others on the one GPU (seeds 1000 .. 1000 + k - 1; chain 0 = the run above)
-    for k in (2, 4):
+    for k in (2, 4, 8):
         key = 'r400_auto_x%d' % k
         try:
             out[key] = bayes_multi_case(400, 'auto', k, samples, burn, device,
                                         single_sha=out.get('r400_auto', {}).get('trace_sha256'))
         except Exception as e:
             out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
-    best = max((out[k] for k in ('r400_auto', 'r400_auto_x2', 'r400_auto_x4') if 'evaluations_per_hour' in out.get(k, {})),
+    best = max((out[k] for k in ('r400_auto', 'r400_auto_x2', 'r400_auto_x4', 'r400_auto_x8') if 'evaluations_per_hour' in out.get(k, {})),
                key=lambda r: r['evaluations_per_hour'], default=None)
     if best is not None:
         out['per_gpu'] = {'evaluations_per_hour': best['evaluations_per_hour'], 'samples_per_hour': best['value'],
@@ -363,6 +363,69 @@ def prob_mass_roofline(device=None, rad_res=400, reps=10):
         except Exception as e:       # a malformed summary must not cost the record
             rec['hbm'] = {'error': str(e)}
     return rec
+
+
+# --------------------------------------------------------------------------- multi-day release (r_dur = 5)
+def release_case(R, mode, rad_dist=10000.0, nd=30, reps=3):
+    """`Run.py --carnarvon --pop` -- the reference's default Carnarvon preset, r_dur = 5 (Run.py:118) -- on the
+    chain API (ps_chain_run_release): end to end through Run.run_model (kernels from the device prob_mass,
+    CSR export of every day included), and the device part alone: the 25 days after the release, each one
+    cohort step + 4 back-solves + the weighted population, enqueued as ONE run."""
+    from parasitoids_amd import CalcSol, globalvars, hip_lib, Run
+    from parasitoids_amd import ParasitoidModel as PM
+    p = Run.Params(config=None)
+    p.cmd_line_chg(['--carnarvon', '--pop', 'domain_info=(%r,%d)' % (rad_dist, R), 'ndays=%d' % nd])
+    old = globalvars.fft_mode
+    globalvars.fft_mode = mode
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            t0 = time.perf_counter()
+            modelsol, days, ndays, tm = Run.run_model(p, verbose=False)
+            t_all = time.perf_counter() - t0
+            route = CalcSol.last_release_route
+            wind_data, days2 = PM.get_wind_data(*p.get_wind_params())
+            starts = [p.r_start] + [None] * (ndays - 1)
+            pmf_list = PM.prob_mass_batch(days2[:ndays], wind_data, *p.get_model_params(), start_times=starts)
+    finally:
+        globalvars.fft_mode = old
+    N = 2 * R + 1
+    ms = np.max([q.shape for q in pmf_list], axis=0)
+    r_spread = [Run.recentre(pmf_list[d], R).tocsr() for d in range(p.r_dur)]
+    rec = {'rad_res': R, 'grid': '%d^2' % N, 'rad_dist': rad_dist, 'r_dur': p.r_dur, 'days': ndays, 'mode_asked': mode,
+           'route': route, 'end_to_end_s': round(t_all, 3), 'prob_mass_s': round(tm['prob_mass_s'], 3),
+           'get_populations_s': round(tm['solver_s'], 3), 'last_day_total': round(float(modelsol[-1].sum()), 3)}
+    s = hip_lib.HipSolve(r_spread[-1], ms, mode='fast' if mode == 'fast' else mode, chain_only=True)
+    try:
+        if s.mode != 'fold' and s.set_release(pmf_list[p.r_dur:ndays], r_spread[:-1]):
+            nk = ndays - p.r_dur
+            w = [p.r_mthd()(d + 1) * p.r_number for d in range(p.r_dur)]
+            ok = True
+            for i in range(reps + 1):
+                if i == 1:
+                    s.sync()
+                    t0 = time.perf_counter()
+                s.set_state(r_spread[-1])
+                ok = s.run_release(0, nk, w) and ok
+            s.sync()
+            dt = (time.perf_counter() - t0) / reps
+            rec['device_chain'] = {'ms': round(dt * 1e3, 3), 'days': nk, 'grid_days_per_s': round(nk / dt, 1),
+                                   'conv_steps_per_s': round(nk * p.r_dur / dt, 1), 'fft_len': s.fft_len,
+                                   'mode': s.mode, 'certified_exact': bool(ok) if s.mode == 'auto' else None}
+    finally:
+        s.close()
+    return rec
+
+
+def release_record():
+    out = {'workload': 'Run.py --carnarvon --pop (r_dur = 5, 40 000 wasps, uniform emergence), 30 days; one grid-day = '
+                       'one cohort step + 4 back-solves + the weighted population (CalcSol.py:308-323)'}
+    for R, mode in ((512, 'fast'), (512, 'auto'), (2048, 'fast')):
+        try:
+            out['r%d_%s' % (R, mode)] = release_case(R, mode)
+        except Exception as e:
+            out['r%d_%s' % (R, mode)] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
 
 
 # --------------------------------------------------------------------------- N > 1: configs 4 and 5
@@ -484,5 +547,7 @@ if __name__ == '__main__':
         print(json.dumps(real_wind_record(R=R)))
     elif which == 'prob_mass':
         print(json.dumps(prob_mass_roofline()))
+    elif which == 'release':
+        print(json.dumps(release_record()))
     else:
         print(json.dumps(bayes_record()))

@@ -161,6 +161,26 @@ int ps_chain_run(ps_solver* s, int first, int count, double negval, double stat_
                  int renorm);
 int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out); /* synchronises */
 
+/* get_populations with a multi-day release, r_dur > 1 (CalcSol.py:296-323; CudaSolve.back_solve,
+ * cuda_lib.py:145-221, with its re-FFT semantics :208-214) on the chain API.  The LAST `nfilt`
+ * entries of the uploaded kernel list are the release days' spreads r_spread[0 .. nfilt-1] in
+ * chronological order, each cut to its support box about the centre (an odd kernel; it lands on the
+ * torus where the reference wraps the N x N filter, CalcSol.py:86-91); the entries before them are
+ * the day kernels.
+ *   count > 0: for each day d of [first, first+count): the last cohort moves one day on (state *=
+ *     K_d, inverse, truncate + re-transform on its flag), the back-solve runs through filters
+ *     nuse-1 .. 0 from a copy of the state's spectrum, and the population
+ *     sum_{i<nuse} weights[i] back_i + weights[nuse] cohort  becomes chain record d (its statistics:
+ *     ps_chain_stats, scale 1, no renormalisation).
+ *   count == 0: the back-solve alone from the state as it stands (a release day, CalcSol.py:298-306):
+ *     sum_{i<nuse} weights[i] back_i + weights[nuse] state  ->  record (3, 0).
+ * Enqueued without a host round trip per day.  *certified (may be NULL): PS_MODE_AUTO -- 1 when no
+ * field of the run had anything above 1e-15 outside the domain, so the fast torus held what the
+ * reference's torus holds (<= 4e-15 per day); 0: redo the run in PS_MODE_EXACT.  Other modes: 1.
+ * PS_MODE_FOLD: PS_ERR_UNSUPPORTED. */
+int ps_chain_run_release(ps_solver* s, int first, int count, double negval, int nfilt, int nuse,
+                         const double* weights, int* certified);
+
 /* ---- records (device-resident N x N fields) ----
  * kind 0: chain/get_cursol records, 1: back_solve records, 2: state (first day),
  * 3: scratch result of ps_weighted_sum. */

@@ -139,6 +139,57 @@ def get_solutions(modelsol, pmf_list, days, ndays, dom_len, max_shape):
         solver.close()
 
 
+# diagnostic: which route the last get_populations(r_dur > 1) took -- 'chain' (ps_chain_run_release),
+# 'chain-uncertified' (an 'auto' run that had to be redone) or 'per-call'
+last_release_route = None
+
+
+def _release_on_chain(r_spread, pmf_list, days, ndays, dom_len, max_shape, r_dur, r_number, dist):
+    '''get_populations for r_dur > 1 through the chain API (ps_chain_run_release): the day kernels and
+    the release days' spreads go to the device once, every release day is one back-solve call and all
+    days after the release ONE enqueued run -- no per-day host COO upload, no per-day synchronisation.
+    The default mode ('auto') runs on the fast torus and certifies afterwards that nothing above 1e-15
+    ever lay outside the domain (then it IS the exact-torus result); an uncertified run, a filter
+    wider than max_shape or a mode without this entry point returns None and the caller takes the
+    per-call route (CalcSol.py:296-323 literally).'''
+    hip_lib = _hip()
+    mode = globalvars.fft_mode
+    if mode == 'fold':
+        return None
+    mid = dom_len // 2
+    nk = len(days[r_dur:ndays])
+    solver = hip_lib.HipSolve(r_spread[0], max_shape, mode=mode, chain_only=True)
+    try:
+        if solver.mode == 'fold' or not solver.set_release(pmf_list[r_dur:r_dur + nk], r_spread[:r_dur - 1]):
+            return None
+        popmodel = []
+        st = solver.record_stats(L.REC_STATE, 0, 1e-8, 1.0, False)
+        first = solver._fetch(L.REC_STATE, 0, 1e-8, 1.0, 0.0, r_number * dist(1), st.nnz, 'csr')
+        first[mid, mid] += r_number * (1 - dist(1))
+        popmodel.append(first)
+        # successive release days (CalcSol.py:296-306)
+        for day in range(1, r_dur):
+            solver.set_state(r_spread[day])
+            w = [dist(d + 1) * r_number for d in range(day + 1)]
+            if not solver.run_release(0, 0, w, nuse=day):
+                return None
+            stw = solver.record_stats(L.REC_WSUM, 0, 1e-8, 1.0, False)
+            pop = solver._fetch(L.REC_WSUM, 0, 1e-8, 1.0, 0.0, 1.0, stw.nnz, 'csr')
+            pop[mid, mid] += (1 - sum(dist(d + 1) for d in range(day + 1))) * r_number
+            popmodel.append(pop)
+        # days after the release (CalcSol.py:308-323): one enqueued run
+        if nk:
+            w = [dist(d + 1) * r_number for d in range(r_dur)]
+            if not solver.run_release(0, nk, w):
+                return None
+            stats = solver.chain_stats(0, nk)
+            for n in range(nk):
+                popmodel.append(solver._fetch(L.REC_CHAIN, n, 1e-8, 1.0, 0.0, 1.0, stats[n].nnz, 'csr'))
+        return popmodel
+    finally:
+        solver.close()
+
+
 def get_populations(r_spread, pmf_list, days, ndays, dom_len, max_shape,
                     r_dur, r_number, dist):
     '''Find expected wasp densities from a list of daily probability densities, given
@@ -149,6 +200,13 @@ def get_populations(r_spread, pmf_list, days, ndays, dom_len, max_shape,
     _need_device_backend()
     hip_lib = _hip()
     mid = dom_len // 2
+    global last_release_route
+    if r_dur > 1:
+        pop = _release_on_chain(r_spread, pmf_list, days, ndays, dom_len, max_shape, r_dur, r_number, dist)
+        if pop is not None:
+            last_release_route = 'chain'
+            return pop
+        last_release_route = 'per-call'
     popmodel = []
     solver = hip_lib.HipSolve(r_spread[0], max_shape, mode=globalvars.fft_mode, chain_only=(r_dur == 1))
     try:

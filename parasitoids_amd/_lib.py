@@ -69,6 +69,8 @@ SIGNATURES = {
     'ps_chain_set_kernels': (C.c_int, [_VP, C.c_int, _I64P, _I32P, _I32P, _I32P, _F64P]),
     'ps_chain_run': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     'ps_chain_stats': (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(DayStats)]),
+    'ps_chain_run_release': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _F64P,
+                                       C.POINTER(C.c_int)]),
     'ps_record_stats': (C.c_int, [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.POINTER(DayStats)]),
     'ps_solver_retarget': (C.c_int, [_VP, C.c_int]),

@@ -2073,8 +2073,16 @@ static int chain_run_body(ps_solver* s, int first, int count, double negval, dou
                                     : (s->kt_direct ? std::min(s->fused_days, direct_days) : s->fused_days);
           if (maxd > 1 && w - i >= 2) {
             // the chained full-column pass takes any number of days; the tiled fused pass 2, 4 or 8
-            const int nd = s->tpipe ? std::min(maxd, w - i)
-                                    : (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
+            int nd = s->tpipe ? std::min(maxd, w - i)
+                              : (maxd >= 8 && w - i >= 8) ? 8 : (maxd >= 4 && w - i >= 4) ? 4 : 2;
+            // a chained group keeps nd intermediates (6.9 GB for 32 days at 5184, per solver -- helper and
+            // shape-class solvers each own theirs): when that does not fit, shorter groups, not an abort
+            // (per-solver footprint: PS_TPIPE_DAYS x one half spectrum)
+            while (nd > 2 && s->T1.ensure((size_t)s->Pf * s->ld * nd) == PS_ERR_OOM) {
+              (void)hipGetLastError();
+              nd = std::max(2, nd / 2);
+              s->cfg.tpipe_days = std::min(s->cfg.tpipe_days, nd);   // and stay there: the memory will not come back mid-run
+            }
             PS_TRY(kernels_ready(s, d + i + nd - 1));
             const cplx* B = s->Bhat.p + (size_t)(d + i - s->bhat_first) * s->Pf * s->ld;
             PS_TRY(conv_inv_multi(s, B, nd, s->Ahat.p, &s->recs[PS_REC_CHAIN][d + i], d + i, negval, stat_scale,
@@ -2304,6 +2312,117 @@ extern "C" int ps_solver_back_solve(ps_solver* s, int nfilt, const int64_t* off,
   }
   s->last_renorm = 0;
   if (stats && nfilt > 0) PS_TRY(ps_chain_stats(s, 0, nfilt, stats));
+  return PS_OK;
+}
+
+// ---- get_populations with a multi-day release (r_dur > 1) on the chain API --------------------
+// CalcSol.py:296-323 / cuda_lib.py:145-221.  The uploaded kernel list is [day kernels ..., filters ...]:
+// its last `nfilt` entries are the release days' spreads r_spread[0 .. nfilt-1] in chronological order,
+// cut to their support box about the centre (odd shapes like any kernel; an N x N filter wrapped about
+// its centre lands on the torus exactly where this kernel does, CalcSol.py:86-91).
+//   count > 0: for every day d of [first, first + count): the cohort of the last release day moves one
+//     day on (state *= K_d, inverse, truncate + re-transform on its flag, CalcSol.py:311-316), then the
+//     back-solve -- a copy of the state's spectrum times filter nuse-1, inverse, flag / re-transform
+//     (cuda_lib.py:208-214 semantics), times filter nuse-2, ... -- and the day's population
+//     sum_i w[i] back_i + w[nuse] cohort  ->  chain record d  (CalcSol.py:322)
+//   count == 0: the back-solve alone, from the state as it stands (a release day, CalcSol.py:298-306):
+//     sum_i w[i] back_i + w[nuse] state field  ->  record (PS_REC_WSUM, 0)
+// Everything is enqueued; no host round trip per day.  *certified (optional): PS_MODE_AUTO -- 1 when
+// no field of the run (cohort or back-solve) had anything above 1e-15 outside the domain, i.e. the fast
+// torus held exactly what the reference's torus holds; 0 tells the caller to redo the run on the exact
+// torus.  Other modes: 1.
+extern "C" int ps_chain_run_release(ps_solver* s, int first, int count, double negval, int nfilt, int nuse,
+                                    const double* weights, int* certified) {
+  if (!s || !weights || nfilt < 0 || nuse < 0 || nuse > nfilt || count < 0 || first < 0)
+    return ps_fail(PS_ERR_BAD_ARG, "run_release: bad arguments");
+  if (s->mode == PS_MODE_FOLD) return ps_fail(PS_ERR_UNSUPPORTED, "run_release: not offered in PS_MODE_FOLD");
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "run_release before set_state");
+  const int ndays = s->nk - nfilt;          // day kernels [0, ndays), filters [ndays, nk)
+  if (!s->kernels_on_device || ndays < 0 || first + count > ndays)
+    return ps_fail(PS_ERR_STATE, "run_release: days [%d,%d) + %d filters not uploaded (nk=%d)", first, first + count, nfilt, s->nk);
+  PS_HIP(hipSetDevice(s->device));
+  if (certified) *certified = 1;
+  const size_t spec = (size_t)s->Pf * s->ld;
+  const int per = nuse + 1;                  // fields per unit of work: the cohort's + nuse back-solves
+  const int units = std::max(1, count);
+  // statistics slots: [0, nk) the population days, then one slot per (unit, field) so that every pad
+  // maximum of the run survives until the end (the auto-mode certificate reads them all)
+  const int slot0 = std::max(4, s->nk);
+  PS_TRY(ensure_stats(s, slot0 + units * per));
+  PS_TRY(ensure_temps(s, 1));
+  PS_TRY(s->Chat.ensure(spec));
+  PS_TRY(ensure_record(s, PS_REC_STATE, 1));                       // the cohort's field of the day
+  for (int i = 0; i < nuse; ++i) PS_TRY(ensure_record(s, PS_REC_BACK, i));
+  for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
+  if (count == 0) PS_TRY(ensure_record(s, PS_REC_WSUM, 0));
+  PS_HIP(hipMemsetAsync(s->padmax.p + slot0, 0, (size_t)units * per * sizeof(unsigned long long), s->stream));
+  if (count > 0) PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
+  s->last_renorm = 0;
+  PS_TRY(resolve_refft(s));
+  if (s->tpipe_ok && !s->spec_valid) set_pipeline(s, true);
+  PS_TRY(ensure_spectrum(s));
+  // transforms: the run's day kernels and the filters side by side in one buffer, ONE format
+  // (direct_chunk = 0: no direct-sum route, the two halves of the buffer are consumed alike)
+  if (count > s->chunk_days) return ps_fail(PS_ERR_UNSUPPORTED, "run_release: %d days exceed one chunk of kernel spectra (%d)", count, s->chunk_days);
+  const int total = count + nuse;
+  if (count > 0) PS_TRY(transform_kernels(s, first, count, 0, total, 0));
+  if (nuse > 0) PS_TRY(transform_kernels(s, ndays, nuse, count, total, 0));
+  s->bhat_first = -1;                        // the buffer is not a plain run of days: nothing to reuse
+  s->bhat_count = 0;
+  // the weighted sum's pointer / weight tables are the same every day
+  {
+    std::vector<const double*> ptrs(per);
+    for (int i = 0; i < nuse; ++i) ptrs[i] = s->recs[PS_REC_BACK][i];
+    ptrs[nuse] = count > 0 ? s->recs[PS_REC_STATE][1] : s->recs[PS_REC_STATE][0];
+    PS_TRY(s->wptr.ensure(per));
+    PS_TRY(s->wval.ensure(per));
+    PS_HIP(hipMemcpyAsync(s->wptr.p, ptrs.data(), per * sizeof(double*), hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipMemcpyAsync(s->wval.p, weights, per * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    PS_HIP(hipStreamSynchronize(s->stream));   // host temporaries
+  }
+  const int64_t tot = (int64_t)s->N * s->N;
+  for (int u = 0; u < units; ++u) {
+    const int d = first + u, sl = slot0 + u * per;
+    if (count > 0) {
+      const cplx* B = s->Bhat.p + (size_t)u * spec;
+      double* rec = s->recs[PS_REC_STATE][1];
+      PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, sl + nuse, negval, 1.0, s->krange.p + 2 * d));
+      PS_TRY(refft_if_flag(s, rec, s->Ahat.p, sl + nuse));
+    }
+    if (nuse > 0) PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
+    for (int i = nuse - 1; i >= 0; --i) {
+      const cplx* F = s->Bhat.p + (size_t)(count + i) * spec;
+      double* rec = s->recs[PS_REC_BACK][i];
+      PS_TRY(conv_inv(s, F, s->Chat.p, 1, rec, sl + i, negval, 1.0, s->krange.p + 2 * (ndays + i)));
+      PS_TRY(refft_if_flag(s, rec, s->Chat.p, sl + i));
+    }
+    double* out = count > 0 ? s->recs[PS_REC_CHAIN][d] : s->recs[PS_REC_WSUM][0];
+    hipLaunchKernelGGL(k_weighted_sum, dim3(2048), dim3(256), 0, s->stream, (const double* const*)s->wptr.p,
+                       s->wval.p, per, tot, out);
+    PS_HIP(hipGetLastError());
+    if (count > 0) {   // the day's statistics (r_small_vals on the population, no renormalisation)
+      hipLaunchKernelGGL(k_row_stats, dim3(s->N), dim3(256), 0, s->stream, out, s->N, 1.0, negval,
+                         s->rowsum.p + (int64_t)d * s->N, s->rowcnt.p + (int64_t)d * s->N);
+      PS_HIP(hipGetLastError());
+    }
+  }
+  s->noflag_hint = 0;
+  s->hist_count = 0;
+  if (s->auto_exact) {
+    // the certificate: every pad maximum of the run below kCleanEps (the inverse row pass of an auto
+    // front publishes maxima above 0.5e-15)
+    std::vector<unsigned long long> h((size_t)units * per);
+    PS_HIP(hipMemcpyAsync(h.data(), s->padmax.p + slot0, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    PS_HIP(hipStreamSynchronize(s->stream));
+    int ok = 1;
+    for (unsigned long long v : h) {
+      double m;
+      __builtin_memcpy(&m, &v, sizeof(double));
+      if (!(m < kCleanEps)) ok = 0;
+    }
+    if (certified) *certified = ok;
+    s->auto_first = -1;
+  }
   return PS_OK;
 }
 

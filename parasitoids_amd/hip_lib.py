@@ -240,6 +240,44 @@ class HipSolve():
                                                L.p_i32(row), L.p_i32(col), L.p_f64(val)))
         self._nk = len(ks)
 
+    def set_release(self, pmf_days, r_spread):
+        '''Kernels of a multi-day release on the chain API (get_populations with r_dur > 1,
+        CalcSol.py:296-323): the day kernels followed by the release days' spreads as back-solve
+        filters -- each N x N spread cut to its support box about the centre, an odd kernel that lands
+        on the torus exactly where the reference wraps the whole filter (CalcSol.py:86-91).  Returns
+        False (nothing uploaded) when a filter reaches further from the centre than max_shape // 2:
+        the caller then keeps the per-call back_solve.'''
+        M = self.pad_shape[0] - self.dom_len
+        mid = self.dom_len // 2
+        filt = []
+        for F in r_spread:
+            F = sparse.coo_matrix(F)
+            if F.shape != (self.dom_len, self.dom_len):
+                raise ValueError('release filters must be dom_len x dom_len')
+            h = int(max(np.abs(F.row - mid).max(), np.abs(F.col - mid).max())) if F.nnz else 0
+            if h > M:
+                return False
+            filt.append(sparse.coo_matrix((F.data, (F.row - mid + h, F.col - mid + h)),
+                                          shape=(2 * h + 1, 2 * h + 1)))
+        self.set_kernels(list(pmf_days) + filt)
+        self._nfilt = len(filt)
+        return True
+
+    def run_release(self, first, count, weights, nuse=None, negval=1e-8):
+        '''Days [first, first+count) of a multi-day release (ps_chain_run_release): per day the last
+        cohort's step, the back-solve through the filters and the population
+        sum_i weights[i] back_i + weights[nuse] cohort -> chain record d; count = 0: the back-solve of
+        the current state alone -> record (REC_WSUM, 0).  Returns False when an 'auto' solver could
+        not certify the run as exact on its fast torus (redo it in 'exact' mode).'''
+        nuse = self._nfilt if nuse is None else nuse
+        w = L.f64(weights)
+        if len(w) != nuse + 1:
+            raise ValueError('need nuse + 1 weights')
+        ok = C.c_int(1)
+        L.check(self._lib.ps_chain_run_release(self._h, first, count, negval, self._nfilt, nuse,
+                                               L.p_f64(w), C.byref(ok)))
+        return bool(ok.value)
+
     def run_chain(self, first=0, count=None, negval=1e-8, scale=1.0, renorm=True):
         '''Enqueue days [first, first+count) of the uploaded kernels (no host sync).'''
         count = self._nk - first if count is None else count

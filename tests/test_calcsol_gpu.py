@@ -211,3 +211,65 @@ def test_baseline_config2_population_model_1024(golden_dir, rad_dist):
         assert 27000.0 < modelsol[-1].sum() < 27400.0, modelsol[-1].sum()    # mass has left (flags fired)
     else:
         assert modelsol[-1].sum() > 0.999 * p.r_number
+
+
+@pytest.mark.parametrize('mode', ['fast', 'auto'])
+def test_multi_day_release_on_the_chain_api(golden_dir, mode):
+    """get_populations with r_dur = 5 (the reference's default Carnarvon preset, Run.py:118) through
+    ps_chain_run_release -- day kernels and release-day filters uploaded once, every day after the release
+    enqueued without a host round trip (CalcSol.py:296-323, cuda_lib.py:145-221) -- against the oracle's
+    get_populations on the same kernels, at a domain where the flag FIRES in the cohort and in the
+    back-solves (10 km, R = 128).  'fast': the chain route, fast-torus tolerance.  'auto': the fast torus
+    cannot certify this run (dust outside the domain), the exact per-call route takes over: 1e-7 on
+    populations up to 8000 per cohort (1e-11 relative).  The flag-free 40 km run of G8
+    (test_run_pop_model_carnarvon_rdur5) is the certified 'auto' chain route against the reference."""
+    from oracle import calcsol as OC
+    from parasitoids_amd import CalcSol, globalvars
+    from parasitoids_amd import ParasitoidModel as PM
+    Run, p = _params(golden_dir, '--carnarvon', '--pop', 'ndays=12', 'domain_info=(10000.0,128)')
+    assert p.r_dur == 5
+    old = globalvars.fft_mode
+    globalvars.fft_mode = mode
+    try:
+        modelsol, days, ndays, _ = Run.run_model(p, verbose=False)
+    finally:
+        globalvars.fft_mode = old
+    assert ndays == 12 and len(modelsol) == 12
+    assert CalcSol.last_release_route == ('chain' if mode == 'fast' else 'per-call')
+    wind_data, days2 = PM.get_wind_data(*p.get_wind_params())
+    starts = [p.r_start] + [None] * (ndays - 1)
+    pmf_list = PM.prob_mass_batch(days2[:ndays], wind_data, *p.get_model_params(), start_times=starts)
+    max_shape = np.array([0, 0])
+    for pmf in pmf_list:
+        max_shape = np.maximum(max_shape, pmf.shape)
+    r_spread = [recentre(pmf_list[d], 128).tocsr() for d in range(p.r_dur)]
+    trace = {}
+    ref = OC.get_populations(r_spread, pmf_list, days2, ndays, 257, max_shape, p.r_dur, p.r_number,
+                             p.r_mthd(), trace=trace)
+    tol = 1e-7 if mode == 'auto' else 5e-8 * p.r_number       # fast torus: <= 1e-8 per un-flagged field (DESIGN 5)
+    for i, (a, b) in enumerate(zip(modelsol, ref)):
+        d = abs(a.tocsr() - b.tocsr())
+        assert (d.max() if d.nnz else 0.0) < tol, (mode, i)
+    assert modelsol[-1].sum() < 0.999 * p.r_number            # mass has left: flags did fire
+
+
+def test_multi_day_release_certified_chain_route(golden, golden_dir):
+    """The G8 run (Carnarvon r_dur = 5, 40 km: nothing reaches the pad) takes the chain route in the
+    default 'auto' mode and is certified exact; forced through the per-call route it gives the same
+    populations to round-off."""
+    from parasitoids_amd import CalcSol
+    Run, p = _params(golden_dir, '--carnarvon', '--pop', 'ndays=10', 'domain_info=(40000.0,200)')
+    a, _, _, _ = Run.run_model(p, verbose=False)
+    assert CalcSol.last_release_route == 'chain'
+    orig = CalcSol._release_on_chain
+    CalcSol._release_on_chain = lambda *args: None
+    try:
+        b, _, _, _ = Run.run_model(p, verbose=False)
+    finally:
+        CalcSol._release_on_chain = orig
+    assert CalcSol.last_release_route == 'per-call'
+    g = golden('g8_back_solve')
+    for i, (x, y) in enumerate(zip(a, b)):
+        d = abs(x.tocsr() - y.tocsr())
+        assert (d.max() if d.nnz else 0.0) < 1e-8, i
+        assert_summary(g, 'car_sum%d' % i, x, g['car_pos'], rtol=1e-9, atol=1e-7, nnz_slack=4)

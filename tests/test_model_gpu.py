@@ -237,3 +237,29 @@ def test_prob_mass_pair_list_overflow_is_redone(PM, kalbar, monkeypatch):
         for x, y in zip(a, b):
             assert x.shape == y.shape and x.nnz == y.nnz
             assert np.array_equal(x.row, y.row) and np.array_equal(x.col, y.col) and np.array_equal(x.data, y.data)
+
+
+def test_prob_mass_day_does_not_depend_on_its_batch_beyond_round_off(PM, kalbar):
+    '''with PS_PM_SEG = 8 (default) eight periods are summed per record before the
+    ordered per-tile pass, and the runs start at multiples of 8 of the CHUNK-global pair index -- so how a
+    tile's periods are grouped depends on the pair counts of the tiles and days ahead of it in the batch.
+    The grouping changes the order of a few additions, nothing else: a day built alone and the same day
+    built behind two others agree to 1e-15 with the same COO pattern; with PS_PM_SEG = 1 (strictly
+    sequential sums, the reference's order) they are bit-identical.'''
+    wd, days = kalbar
+    for seg, exact in ((8, False), (1, True)):
+        m = PM.WindModel(wd)
+        m.set_option('PS_PM_SEG', seg)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            m.build([days[2]], HP, DP, DLP, MU_R, NPER, 10000.0, 128)
+            alone = m.fetch(0)
+            m.build(days[:3], HP, DP, DLP, MU_R, NPER, 10000.0, 128)
+            batched = m.fetch(2)
+        m.close()
+        assert alone.shape == batched.shape and alone.nnz == batched.nnz
+        assert np.array_equal(alone.row, batched.row) and np.array_equal(alone.col, batched.col)
+        if exact:
+            assert np.array_equal(alone.data, batched.data)
+        else:
+            assert np.abs(alone.data - batched.data).max() < 1e-15
