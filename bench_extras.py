@@ -82,7 +82,7 @@ def real_wind_case(rad_dist, R=2048, nd=30, mode='fast', device=None, reps=3, pr
            'auto_first_fold_day': s.auto_info()[0] if s.mode == 'auto' else None,
            'auto_fold_fft': s.auto_info()[1] if s.mode == 'auto' else None,
            'auto_route_days': ({k: int((s.auto_route(0, nd - 1) == v).sum()) for k, v in
-                                (('front', 0), ('wide', 1), ('fold', 2))} if s.mode == 'auto' else None),
+                                (('front', 0), ('wide', 1), ('fold', 2), ('narrow', 3))} if s.mode == 'auto' else None),
            'multi_day_launches': {k: v['launches_per_chain'] for k, v in kern.items() if k.startswith('col_inv_a_x')},
            'end_to_end_eval_s': round(t_eval, 4), 'first_eval_s': round(t_first, 3),
            'last_day_mass': round(last.sum + last.delta * last.nnz, 12), 'last_day_nnz': int(last.nnz),
@@ -510,6 +510,46 @@ def multi_gpu_record(rank, world, device=None, rehearse=False, members_per_rank=
                            'per_rank_members_per_s': [round(n / t, 3) for _, n, t in sorted(times)],
                            'members_gathered': len(res),
                            'all_members_conserve_mass': bool(all(abs(r['total'] - 1.0) < 1e-6 or r['total'] < 1.0 + 1e-9 for r in res))}
+    # ---- one simulation's kernel construction sharded over the ranks (Run.py:412-425): days
+    # round-robin, COO triplets all-gathered device to device (RCCL over xGMI), every rank ends with
+    # all kernels on its GPU.  Timed next to one rank building all days itself.
+    del errors[:]
+    shard = None
+    if not rehearse:
+        def sharded():
+            import torch
+            from parasitoids_amd import ParasitoidModel as PM
+            wd, days = PM.get_wind_data('data/carnarvonearl', 30, '00:30')
+            m = PM.WindModel(wd, device=device)
+            prm = (HP, DP, DLP, MU_R, NPER, 10000.0, rad_res)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore', RuntimeWarning)
+                parallel.prob_mass_sharded_device(m, days[:ndays], prm)        # warm-up (lists, buffers)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                g = parallel.prob_mass_sharded_device(m, days[:ndays], prm)
+                torch.cuda.synchronize()
+                t_sh = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                m.build(days[:ndays], *prm)
+                t_one = time.perf_counter() - t0
+            m.close()
+            return {'sharded_s': t_sh, 'one_gpu_s': t_one, 'entries': int(g['off'][-1]), 'days': ndays}
+        shard = guarded('sharded prob_mass', sharded, None)
+    barrier()
+    shards = parallel.gather_objects((rank, shard, list(errors)))
+    if rank == 0 and not rehearse:
+        if any(sh is None for _, sh, _ in shards):
+            out['sharded_prob_mass'] = {'error': [m for _, _, e in shards for m in e]}
+        else:
+            t_sh = max(sh['sharded_s'] for _, sh, _ in shards)
+            t_one = max(sh['one_gpu_s'] for _, sh, _ in shards)
+            out['sharded_prob_mass'] = {
+                'workload': '%d Carnarvon day kernels at %d^2, days round-robin over %d ranks, triplets all-gathered '
+                            'device to device' % (ndays, 2 * rad_res + 1, world),
+                'seconds': round(t_sh, 4), 'one_gpu_builds_all_days_s': round(t_one, 4),
+                'speedup': round(t_one / t_sh, 2), 'coo_entries': shards[0][1]['entries'],
+                'bytes_gathered_per_rank': shards[0][1]['entries'] * 16}
     # ---- config 4
     seed = 1000 + rank
     del errors[:]

@@ -111,7 +111,9 @@ int ps_solver_pipeline(ps_solver* s);
 int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_fft);
 /* PS_MODE_AUTO: which solver produced each day [first, first+count) of the last ps_chain_run:
  * 0 the fast-torus front (clean prefix), 1 the wide fast-torus helper (N + 2M: flagged and clean
- * days past the prefix), 2 the fold child (days whose sub-threshold dust the reference carries). */
+ * days past the prefix), 2 the fold child (days whose sub-threshold dust the reference carries),
+ * 3 the narrow fast-torus helper (N + M, like the front: days a previous run saw flagged above 4e-8,
+ * which makes the reference's flag certain on any torus). */
 int ps_solver_auto_route(ps_solver* s, int first, int count, int32_t* owner);
 
 /* CudaSolve.__init__ (cuda_lib.py:34-54) / CalcSol.fft2 (CalcSol.py:11-24):
@@ -275,6 +277,22 @@ int ps_model_mvn_cdf_values(ps_model* m, double cell, double mu_x, double mu_y, 
  * (no host round trip): equivalent to ps_chain_set_kernels with days [first, first+count). */
 int ps_chain_set_kernels_from_model(ps_solver* s, ps_model* m, int first, int count);
 int ps_solver_set_state_from_model(ps_solver* s, ps_model* m, int i);
+
+/* ---- device-resident exchange between ranks (Run.py:412-425 maps prob_mass over a process pool; here
+ * the days are sharded over the GPUs of a node and the COO kernels all-gathered with RCCL over xGMI).
+ * The library does not know the communicator: the caller owns the device buffers of the collective and
+ * passes raw DEVICE pointers (the only entry points that take device memory from outside).
+ *   ps_model_export_device      concatenated triplets (int32 row, int32 col, float64 val) of days
+ *                               [first, first+count) of the last batch -> caller's buffers (cap entries)
+ *   ps_chain_set_kernels_device ps_chain_set_kernels from device triplets (copied before return)
+ *   ps_solver_set_state_device  ps_solver_set_state_coo from the device triplets of an odd
+ *                               kshape x kshape kernel, re-centred into the domain (Run.py:454-458) */
+int ps_model_export_device(ps_model* m, int first, int count, void* row_dev, void* col_dev, void* val_dev,
+                           int64_t cap);
+int ps_chain_set_kernels_device(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                                const void* row_dev, const void* col_dev, const void* val_dev);
+int ps_solver_set_state_device(ps_solver* s, const void* row_dev, const void* col_dev, const void* val_dev,
+                               int64_t nnz, int kshape);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,9 @@ SIGNATURES = {
                                           C.c_double, C.c_double, _I32P, _F64P, C.c_int64]),
     'ps_chain_set_kernels_from_model': (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     'ps_solver_set_state_from_model': (C.c_int, [_VP, _VP, C.c_int]),
+    'ps_model_export_device': (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, C.c_int64]),
+    'ps_chain_set_kernels_device': (C.c_int, [_VP, C.c_int, _I64P, _I32P, _VP, _VP, _VP]),
+    'ps_solver_set_state_device': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
 }
 
 _lib = None

@@ -472,6 +472,53 @@ extern "C" int ps_chain_set_kernels_from_model(ps_solver* s, ps_model* m, int fi
                                        m->ocol.p + m->off[first], m->oval.p + m->off[first]);
 }
 
+// ---- device-resident exchange of day kernels between ranks (days sharded over the GPUs, the
+// COO triplets all-gathered with RCCL).  The library neither owns nor sees the communicator: the caller
+// (parallel.prob_mass_sharded_device) hands in device buffers it allocated for the collective -- raw
+// device pointers, e.g. torch tensors' data_ptr() -- and the kernels never pass through host memory.
+extern "C" int ps_model_export_device(ps_model* m, int first, int count, void* row_dev, void* col_dev, void* val_dev,
+                                      int64_t cap) {
+  if (!m || !row_dev || !col_dev || !val_dev) return ps_fail(PS_ERR_BAD_ARG, "export_device: bad arguments");
+  if (first < 0 || count < 0 || first + count > m->nd) return ps_fail(PS_ERR_STATE, "export_device: days [%d,%d) not in the last batch", first, first + count);
+  for (int d = first; d < first + count; ++d)
+    if (m->hinfo[d].status != 0) return ps_fail(m->hinfo[d].status, "day %d of the batch failed its checks", d);
+  const int64_t o = m->off[first], n = m->off[first + count] - o;
+  if (cap < n) return ps_fail(PS_ERR_BAD_ARG, "export_device: capacity %lld < %lld entries", (long long)cap, (long long)n);
+  if (n == 0) return PS_OK;
+  PS_HIP(hipSetDevice(m->device));
+  PS_HIP(hipMemcpyAsync(row_dev, m->orow.p + o, n * 4, hipMemcpyDeviceToDevice, m->stream));
+  PS_HIP(hipMemcpyAsync(col_dev, m->ocol.p + o, n * 4, hipMemcpyDeviceToDevice, m->stream));
+  PS_HIP(hipMemcpyAsync(val_dev, m->oval.p + o, n * 8, hipMemcpyDeviceToDevice, m->stream));
+  PS_HIP(hipStreamSynchronize(m->stream));   // the caller's collective runs on another stream
+  return PS_OK;
+}
+
+// ps_chain_set_kernels with the triplets already in device memory (caller-owned; copied before return)
+extern "C" int ps_chain_set_kernels_device(ps_solver* s, int nk, const int64_t* off, const int32_t* kshape,
+                                           const void* row_dev, const void* col_dev, const void* val_dev) {
+  if (!s || nk < 0 || !off || (nk > 0 && (!kshape || !row_dev || !col_dev || !val_dev)))
+    return ps_fail(PS_ERR_BAD_ARG, "set_kernels_device: bad arguments");
+  for (int d = 0; d < nk; ++d)
+    if (off[d + 1] < off[d]) return ps_fail(PS_ERR_BAD_ARG, "offsets not monotone");
+  PS_HIP(hipSetDevice(ps_solver_device_internal(s)));
+  PS_TRY(ps_chain_adopt_device_kernels(s, nk, off, kshape, (const int*)row_dev, (const int*)col_dev, (const double*)val_dev));
+  return ps_solver_sync(s);                  // the caller may reuse its buffers
+}
+
+// ps_solver_set_state_coo from device triplets of an odd kshape x kshape kernel, re-centred into the
+// domain (Run.py:454-458: offset = rad_res - kshape // 2)
+extern "C" int ps_solver_set_state_device(ps_solver* s, const void* row_dev, const void* col_dev, const void* val_dev,
+                                          int64_t nnz, int kshape) {
+  if (!s || nnz < 0 || (nnz > 0 && (!row_dev || !col_dev || !val_dev)) || kshape < 1 || kshape % 2 == 0)
+    return ps_fail(PS_ERR_BAD_ARG, "set_state_device: bad arguments");
+  const int N = ps_solver_dom_len_internal(s);
+  if (kshape > N) return ps_fail(PS_ERR_BAD_SHAPE, "set_state_device: kernel %d larger than the domain %d", kshape, N);
+  PS_HIP(hipSetDevice(ps_solver_device_internal(s)));
+  PS_TRY(ps_solver_set_state_device_coo(s, (const int*)row_dev, (const int*)col_dev, (const double*)val_dev, nnz,
+                                        N / 2 - kshape / 2));
+  return ps_solver_sync(s);
+}
+
 extern "C" int ps_solver_set_state_from_model(ps_solver* s, ps_model* m, int i) {
   if (!s || !m) return ps_fail(PS_ERR_BAD_ARG, "null handle");
   if (i < 0 || i >= m->nd) return ps_fail(PS_ERR_STATE, "day %d not in the last batch", i);

@@ -251,6 +251,10 @@ struct ps_solver {
   double pad_floor = 0.5e-8;   // inverse row pass publishes pad maxima above this
   ps_solver* child = nullptr;  // fold-mode helper (the reference torus itself)
   ps_solver* wide = nullptr;   // fast-torus helper sized N + 2M (flagged and clean days past the clean prefix)
+  // fast-torus helper on the front's own size (N + M): days that history says are STRONGLY flagged -- more
+  // than 4e-8 outside the domain, which makes the reference's flag certain whatever overlaps (auto_handover)
+  ps_solver* narrow = nullptr;
+  bool narrow_kernels = false;
   bool borrowed = false;       // helper: stream and chain records belong to the parent
   bool child_kernels = false, wide_kernels = false;   // the helper holds the current day kernels
   std::vector<signed char> owner;   // per chain day of the last run: 0 this solver, 1 wide, 2 child
@@ -1133,6 +1137,10 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
     ps_solver_destroy(s->wide);
     s->wide = nullptr;
   }
+  if (s->narrow) {
+    ps_solver_destroy(s->narrow);
+    s->narrow = nullptr;
+  }
   if (s->borrowed) {   // stream and chain records are the parent's
     s->stream = nullptr;
     for (auto& p : s->recs[PS_REC_CHAIN]) p = nullptr;
@@ -1188,6 +1196,11 @@ extern "C" int ps_solver_retarget(ps_solver* s, int max_shape) {
       ps_solver_destroy(s->wide);
       s->wide = nullptr;
     }
+    if (s->narrow) {
+      ps_solver_destroy(s->narrow);
+      s->narrow = nullptr;
+    }
+    s->narrow_kernels = false;
     s->child_kernels = false;
     s->wide_kernels = false;
     s->route_first = s->route_end = -1;   // another torus, another route
@@ -1480,6 +1493,7 @@ static int set_kernels_common(ps_solver* s, int nk, const int64_t* off, const in
   s->kernels_on_device = true;
   s->child_kernels = false;
   s->wide_kernels = false;
+  s->narrow_kernels = false;
   return PS_OK;
 }
 
@@ -1623,7 +1637,10 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   if (!s->cfg.no_route_history && s->route_first == first && s->route_end == end) hist = s->route_hist;
   if ((int)s->owner.size() < end) s->owner.resize(end, 0);
   for (int d = first; d < f; ++d) s->owner[d] = 0;
-  enum { WIDE = 1, CHILD = 2 };
+  enum { WIDE = 1, CHILD = 2, NARROW = 3 };
+  // what the next run should try per day: the owner, except that a wide-torus day whose flag was strong
+  // (or that was clean with room to spare) is marked for the narrow helper
+  std::vector<signed char> hint((size_t)end, 0);
   auto hist_owner = [&](int q) { return q >= 0 && q < (int)hist.size() && q < end ? (int)hist[q] : -1; };
   auto stretch = [&](int q, int who) {   // days from q on that belonged to `who` last time (0: no history)
     int e = q;
@@ -1632,13 +1649,61 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   };
   int regime = (no_wide || !(m_front > 1e-8)) ? CHILD : WIDE;
   s->auto_first_regime = regime;
-  bool wide_live = false, child_live = false;   // the helper's state continues the chain at day d
+  bool wide_live = false, child_live = false, narrow_live = false;   // the helper's state continues the chain at day d
+  int no_narrow_day = -1;     // the narrow torus could not decide this day: the wide one does
   int d = f;
   while (d < end) {
     const double* prev = auto_prev_field(s, first, d);
+    if (regime == NARROW && hist_owner(d) != NARROW) {
+      regime = WIDE;
+      narrow_live = false;
+    }
+    if (regime == WIDE && hist_owner(d) == NARROW && d != no_narrow_day) {
+      regime = NARROW;
+      wide_live = false;
+    }
     if (regime == WIDE && hist_owner(d) == CHILD) {   // dusty last time: do not try the wide torus on it
       regime = CHILD;
       wide_live = false;
+      continue;
+    }
+    if (regime == NARROW) {
+      // A fast torus of the FRONT's size (N + M).  Overhangs overlap there as they do on the reference's
+      // torus, in other places -- but a pad value is a sum of at most four non-negative overhang pieces
+      // on either torus, so with m_f the largest value outside the domain here and m' the largest single
+      // piece: m' <= m_f <= 4 m'.  m_f > 4e-8 makes m' > 1e-8: the reference raises its flag for certain,
+      // truncates, and the domain part (no wrap into the domain on any torus >= N + M_d) is exactly its
+      // field; m_f < 1e-15 is a clean day.  Anything in between goes back to the wide torus.  Only ever
+      // entered on history: a day the wide torus saw above 4e-8 last time (0.55 instead of 0.81 ms at
+      // N = 4097).
+      PS_TRY(auto_attach(s, &s->narrow, PS_MODE_FAST, 2 * s->M + 1, &s->narrow_kernels, end));
+      ps_solver* c = s->narrow;
+      if (!narrow_live) {
+        if (!prev) return ps_fail(PS_ERR_STATE, "auto mode: no field to continue day %d from", d);
+        PS_TRY(ensure_record(c, PS_REC_STATE, 0));
+        PS_HIP(hipMemcpyAsync(c->recs[PS_REC_STATE][0], prev, (size_t)s->N * s->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        c->spec_valid = false;
+        c->srange_valid = false;
+        c->have_state = true;
+        narrow_live = true;
+        wide_live = child_live = false;
+      }
+      const int w = std::min(std::max(1, stretch(d, NARROW)), end - d);
+      PS_TRY(auto_alias_records(s, c, d, d + w));
+      PS_TRY(ps_chain_run(c, d, w, negval, stat_scale, renorm));
+      double m[64];
+      PS_TRY(auto_read_padmax(s, c, d, std::min(w, 64), m));
+      int x = -1;
+      for (int i = 0; i < w && x < 0; ++i)
+        if (m[i] >= kCleanEps && !(m[i] > 4e-8)) x = d + i;
+      const int keep = x < 0 ? d + w : x;
+      for (int q = d; q < keep; ++q) s->owner[q] = hint[q] = NARROW;
+      d = keep;
+      if (x >= 0) {
+        regime = WIDE;
+        narrow_live = false;
+        no_narrow_day = x;
+      }
       continue;
     }
     if (regime == WIDE) {
@@ -1652,7 +1717,7 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
         c->srange_valid = false;   // a whole field: every row may hold something
         c->have_state = true;
         wide_live = true;
-        child_live = false;
+        child_live = narrow_live = false;
       }
       const int hw = stretch(d, WIDE);
       const int w = std::min(hw > 0 ? hw : kWin, end - d);
@@ -1664,7 +1729,11 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
       for (int i = 0; i < w && x < 0; ++i)
         if (m[i] >= kCleanEps && !(m[i] > 1e-8)) x = d + i;     // dust the reference would carry: not ours
       const int keep = x < 0 ? d + w : x;
-      for (int q = d; q < keep; ++q) s->owner[q] = WIDE;
+      for (int q = d; q < keep; ++q) {
+        s->owner[q] = WIDE;
+        const double mq = m[q - d];
+        hint[q] = (mq > 4e-8 || mq < 0.25 * kCleanEps) ? NARROW : WIDE;
+      }
       d = keep;
       if (x >= 0) {
         regime = CHILD;
@@ -1681,7 +1750,7 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
                                 (size_t)s->N * sizeof(double), (size_t)s->N, hipMemcpyDeviceToDevice, c->stream));
         c->have_state = true;
         child_live = true;
-        wide_live = false;
+        wide_live = narrow_live = false;
       }
       const int hc = stretch(d, CHILD);
       const int w = no_wide ? end - d : std::min(hc > 0 ? hc : kWin, end - d);
@@ -1696,7 +1765,7 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
                                                                           // (and not dusty again the day after, last time)
       }
       const int keep = g < 0 ? d + w : g + 1;
-      for (int q = d; q < keep; ++q) s->owner[q] = CHILD;
+      for (int q = d; q < keep; ++q) s->owner[q] = hint[q] = CHILD;
       d = keep;
       if (g >= 0) {
         regime = WIDE;
@@ -1706,7 +1775,7 @@ static int auto_handover(ps_solver* s, int first, int f, int end, double negval,
   }
   s->auto_first = f;
   s->auto_hint = f - first;
-  s->route_hist.assign(s->owner.begin(), s->owner.begin() + end);
+  s->route_hist.assign(hint.begin(), hint.end());
   s->route_first = first;
   s->route_end = end;
   s->have_state = false;   // the front's spectrum is void now: per-call API needs a new state
@@ -2161,7 +2230,7 @@ extern "C" int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* 
       const int o = d < (int)s->owner.size() ? s->owner[d] : 0;
       int e = d + 1;
       while (e < first + count && (e < (int)s->owner.size() ? s->owner[e] : 0) == o) ++e;
-      ps_solver* c = o == 1 ? s->wide : (o == 2 ? s->child : s);
+      ps_solver* c = o == 1 ? s->wide : (o == 2 ? s->child : (o == 3 ? s->narrow : s));
       if (!c) return ps_fail(PS_ERR_STATE, "auto mode: day %d has no owner", d);
       if (c == s) {
         PS_TRY(finalize_days(s, d, e - d, s->last_renorm));
@@ -2654,6 +2723,7 @@ extern "C" int ps_solver_set_option(ps_solver* s, const char* key, double value)
   // the helpers of an auto-mode front follow their parent
   if (s->child) PS_TRY(ps_solver_set_option(s->child, key, value));
   if (s->wide) PS_TRY(ps_solver_set_option(s->wide, key, value));
+  if (s->narrow) PS_TRY(ps_solver_set_option(s->narrow, key, value));
   return PS_OK;
 }
 

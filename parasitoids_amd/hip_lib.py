@@ -132,6 +132,48 @@ class HipSolve():
         self.set_state_from_model(model, i)
         return self
 
+    @classmethod
+    def from_device_kernels(cls, g, i, max_shape, mode='auto', device=None, chain_only=True):
+        '''Solver whose first-day state is kernel `i` of a gathered device kernel set
+        (`parallel.prob_mass_sharded_device`), re-centred into the domain (Run.py:454-458); the other
+        kernels go in with `set_kernels_device`.  Nothing passes through host memory.'''
+        self = cls.__new__(cls)
+        self._h = L._VP()
+        self._lib = L.load()
+        ms = int(np.array(max_shape).ravel()[0])
+        N = int(g['dom_len'])
+        self.dom_len = N
+        self.pad_shape = (N + ms // 2, N + ms // 2)
+        dev = L.default_device() if device is None else device
+        self.mode = _create_solver(self._lib, self._h, dev, N, ms, mode, chain_only)
+        info = [C.c_int32() for _ in range(4)]
+        L.check(self._lib.ps_solver_info(self._h, *[C.byref(v) for v in info]))
+        self.fft_len = info[2].value
+        self._nk = 0
+        self.set_state_device(g, i)
+        return self
+
+    def set_state_device(self, g, i):
+        import torch
+        torch.cuda.synchronize()
+        o, n = int(g['off'][i]), int(g['off'][i + 1] - g['off'][i])
+        L.check(self._lib.ps_solver_set_state_device(
+            self._h, g['row'].data_ptr() + 4 * o, g['col'].data_ptr() + 4 * o, g['val'].data_ptr() + 8 * o,
+            n, int(g['kshape'][i])))
+
+    def set_kernels_device(self, g, first, count):
+        '''Day kernels [first, first+count) of a gathered device kernel set as this solver's chain
+        kernels (ps_chain_set_kernels_device: device to device).'''
+        import torch
+        torch.cuda.synchronize()
+        o = int(g['off'][first])
+        off = np.ascontiguousarray(g['off'][first:first + count + 1] - o, dtype=np.int64)
+        ks = np.ascontiguousarray(g['kshape'][first:first + count], dtype=np.int32)
+        L.check(self._lib.ps_chain_set_kernels_device(
+            self._h, count, L.p_i64(off), L.p_i32(ks), g['row'].data_ptr() + 4 * o,
+            g['col'].data_ptr() + 4 * o, g['val'].data_ptr() + 8 * o))
+        self._nk = count
+
     def retarget(self, max_shape):
         '''fold / auto mode: move the solver to another kernel shape limit / reference torus,
         keeping its FFT size, plans and buffers (the state has to be set again)'''

@@ -194,6 +194,102 @@ def prob_mass_sharded(days, wind_data, model_params, start_times=None, build=Non
     return all_gather_sparse(local, len(days))
 
 
+def all_gather_device(t):
+    """all_gather of a 1-D torch tensor whose length differs per rank; the pieces stay on `t`'s device.
+    RCCL ("nccl") moves them GPU to GPU over xGMI; gloo (the CPU rehearsal backend, which has no
+    all_gather for device tensors) stages through the host."""
+    import torch
+    dist = _dist()
+    rank, world = rank_world()
+    if world == 1:
+        return [t]
+    via_host = t.is_cuda and dist.get_backend() != 'nccl'
+    w = t.cpu() if via_host else t
+    n = torch.tensor([w.numel()], dtype=torch.int64, device=w.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    mx = max(max(sizes), 1)
+    pad = torch.zeros(mx, dtype=w.dtype, device=w.device)
+    pad[:w.numel()] = w
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    outs = [o[:sizes[r]] for r, o in enumerate(outs)]
+    return [o.to(t.device) for o in outs] if via_host else outs
+
+
+def _device_export(model, days, model_params, start_times):
+    """build `days` on this rank's GPU and copy their COO triplets into torch tensors on the same GPU
+    (ps_model_export_device: device to device) -> (kshape list, nnz list, row, col, val)"""
+    import torch
+    from . import _lib as L
+    dev = torch.device('cuda', torch.cuda.current_device())
+    if not days:
+        z = lambda dt: torch.zeros(0, dtype=dt, device=dev)
+        return [], [], z(torch.int32), z(torch.int32), z(torch.float64)
+    kshape, nnz, _, _ = model.build(days, *model_params, start_times)
+    for i in range(len(days)):
+        model.check(i)
+    tot = int(nnz.sum())
+    row = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)
+    col = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(tot, 1), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    L.check(model._lib.ps_model_export_device(model._h, 0, len(days), row.data_ptr(), col.data_ptr(),
+                                              val.data_ptr(), tot))
+    return [int(k) for k in kshape], [int(n) for n in nnz], row[:tot], col[:tot], val[:tot]
+
+
+def prob_mass_sharded_device(model, days, model_params, start_times=None, export=None):
+    """Day kernels for `days` without a host round trip: every rank builds days[rank::world] with its
+    device model, the COO triplets are all-gathered GPU to GPU (RCCL over xGMI under "nccl") and put in
+    day order on every rank's device.  What Run.main's `pool.starmap(prob_mass, ...)` returns
+    (Run.py:412-425), resident where the chain will read it.
+
+    -> dict(kshape=int32[nd], off=int64[nd + 1] (numpy, host: sizes only),
+            row=int32[...], col=int32[...], val=float64[...] (torch tensors on this rank's device))
+    Hand it to `HipSolve.from_device_kernels` / `set_kernels_device`.
+    `export(days, model_params, start_times) -> (kshape, nnz, row, col, val)` replaces the device
+    builder (the CPU rehearsal of the exchange under gloo)."""
+    import torch
+    rank, world = rank_world()
+    nd = len(days)
+    if start_times is None:
+        start_times = [None] * nd
+    mine = list(range(nd))[rank::world]
+    my_days, my_st = [days[i] for i in mine], [start_times[i] for i in mine]
+    if export is None:
+        ks, nz, row, col, val = _device_export(model, my_days, model_params, my_st)
+    else:
+        ks, nz, row, col, val = export(my_days, model_params, my_st)
+    meta = gather_all_objects((ks, nz))
+    rows, cols, vals = all_gather_device(row), all_gather_device(col), all_gather_device(val)
+    kshape = np.zeros(nd, dtype=np.int32)
+    off = np.zeros(nd + 1, dtype=np.int64)
+    pieces = []
+    for i in range(nd):
+        r, k = i % world, i // world
+        lo = int(sum(meta[r][1][:k]))
+        n = int(meta[r][1][k])
+        kshape[i] = meta[r][0][k]
+        off[i + 1] = off[i] + n
+        pieces.append((r, lo, lo + n))
+    cat = lambda parts: torch.cat([parts[r][lo:hi] for r, lo, hi in pieces]) if pieces else parts[0][:0]
+    return dict(kshape=kshape, off=off, row=cat(rows).contiguous(), col=cat(cols).contiguous(),
+                val=cat(vals).contiguous())
+
+
+def gather_all_objects(obj):
+    """all_gather of small python objects (sizes, shapes): every rank gets the list in rank order"""
+    dist = _dist()
+    rank, world = rank_world()
+    if world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def run_members(members, fn, dst=0):
     """Round-robin independent simulations (MCMC chains, ensemble members): member i runs
     on rank i % world; results (small python objects) are gathered on rank dst in member

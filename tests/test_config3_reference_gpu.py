@@ -62,7 +62,13 @@ def test_config3_full_size_against_the_reference(tag, rad_dist, golden, carnarvo
                 assert int(pm.model.last['kshape'].max()) == int(g[tag + '_max_shape'].max())
                 for i in range(ND):
                     check_digest(g, '%s_pmf%d' % (tag, i), pm.model.fetch(i))
-                pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=ND)     # the hinted / history-guided run
+                # the runs a sampler or the bench repeats: the second is guided by the first one's route,
+                # the third also by what the wide helper saw (strong flags go to the narrow helper)
+                pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=ND)
+                pm.evaluate(HP, DP, DLP, MU_R, NPER, ndays=ND)
+                if tag == 'c3a':
+                    route = pm.solver.auto_route(0, ND - 1)
+                    assert set(int(v) for v in route) == {0, 1, 2, 3}, route
         s = pm.solver
         st = pm.stats
         assert [bool(x.flag) for x in st] == ref_flags, mode

@@ -36,8 +36,22 @@ def _worker(rank, world, port, golden_dir, q):
     pmfs = parallel.prob_mass_sharded(days[:5], wd, params, build=build)
     members = [dict(mu_r=1.0 + 0.1 * i) for i in range(5)]
     res = parallel.run_members(members, lambda m: (rank, round(m['mu_r'] * 10)))
+    import torch
     import torch.distributed as dist
-    out = dict(days=days, nnz=[p.nnz for p in pmfs], sums=[float(p.sum()) for p in pmfs],
+    # the device-resident exchange (prob_mass_sharded_device) with a CPU stand-in for the exporter: each
+    # rank contributes the triplets of ITS days only, the result is every day in order on every rank
+    by_day = dict(zip(days[:5], pmfs))
+
+    def export(ds, model_params, sts):
+        mats = [by_day[d].tocoo() for d in ds]
+        cat = lambda xs, dt: torch.from_numpy(np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt))
+        return ([m.shape[0] for m in mats], [m.nnz for m in mats], cat([m.row for m in mats], np.int32),
+                cat([m.col for m in mats], np.int32), cat([m.data for m in mats], np.float64))
+
+    g = parallel.prob_mass_sharded_device(None, days[:5], params, export=export)
+    dev = dict(kshape=g['kshape'].tolist(), off=g['off'].tolist(), row=g['row'].numpy(), col=g['col'].numpy(),
+               val=g['val'].numpy())
+    out = dict(days=days, nnz=[p.nnz for p in pmfs], sums=[float(p.sum()) for p in pmfs], dev=dev,
                shapes=[p.shape for p in pmfs], first=pmfs[0].toarray(), last=pmfs[4].toarray(),
                wind_sum=float(sum(v.sum() for v in wd.values())), res=res)
     q.put((rank, out))
@@ -70,6 +84,12 @@ def test_two_rank_day_sharding_and_member_gather(golden_dir):
         assert o['shapes'] == [p.shape for p in ref]
         assert np.array_equal(o['first'], ref[0].toarray())      # built on rank 0
         assert np.array_equal(o['last'], ref[4].toarray())       # built on rank 0 (4 % 2)
+        d = o['dev']                                             # the device-style exchange: all days, in order
+        assert d['kshape'] == [p.shape[0] for p in ref]
+        assert d['off'] == [0] + list(np.cumsum([p.nnz for p in ref]))
+        assert np.array_equal(d['row'], np.concatenate([p.row for p in ref]))
+        assert np.array_equal(d['col'], np.concatenate([p.col for p in ref]))
+        assert np.array_equal(d['val'], np.concatenate([p.data for p in ref]))
     assert got[1]['res'] is None
     assert got[0]['res'] == [(i % 2, 10 + i) for i in range(5)]  # member i ran on rank i % 2
 

@@ -102,3 +102,58 @@ def test_chains_side_by_side_on_one_gpu_are_bitwise_the_chains_alone():
     for a, b in zip(alone, res):
         assert np.array_equal(a['trace'], b['trace']) and np.array_equal(a['logp'], b['logp'])
         assert b['evaluations_this_run'] == a['evaluations_this_run'] > 0
+
+
+_DEVICE_EXCHANGE = r'''
+import sys, warnings
+import numpy as np
+import torch                      # before the library: one HIP runtime per process (torch's wheel brings its own)
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+from helpers import HP, DP, DLP, MU_R, NPER
+from parasitoids_amd import ParasitoidModel as PM
+from parasitoids_amd import hip_lib, parallel, _lib as L
+warnings.simplefilter('ignore', RuntimeWarning)
+R, nd = 200, 8
+N = 2 * R + 1
+wd, days = PM.get_wind_data('data/kalbar', 30, '00:00')
+model = PM.WindModel(wd)
+params = (HP, DP, DLP, MU_R, NPER, 10000.0, R)
+g = parallel.prob_mass_sharded_device(model, days[:nd], params)
+g['dom_len'] = N
+assert g['row'].is_cuda and g['val'].dtype == torch.float64 and len(g['kshape']) == nd
+for i in (0, 3, nd - 1):
+    ref = model.fetch(i)
+    o, e = int(g['off'][i]), int(g['off'][i + 1])
+    assert ref.shape[0] == g['kshape'][i] and ref.nnz == e - o
+    assert np.array_equal(g['row'][o:e].cpu().numpy(), ref.row) and np.array_equal(g['val'][o:e].cpu().numpy(), ref.data)
+ms = int(g['kshape'].max())
+a = hip_lib.HipSolve.from_device_kernels(g, 0, [ms, ms], mode='fast')
+a.set_kernels_device(g, 1, nd - 1)
+a.run_chain(0, nd - 1, renorm=False, scale=130000.0)
+b = hip_lib.HipSolve.from_model(model, 0, [ms, ms], mode='fast', chain_only=True)
+b.set_kernels_from_model(model, 1, nd - 1)
+b.run_chain(0, nd - 1, renorm=False, scale=130000.0)
+sa, sb = a.chain_stats(0, nd - 1), b.chain_stats(0, nd - 1)
+for d in range(nd - 1):
+    assert (sa[d].nnz, sa[d].sum, sa[d].flag) == (sb[d].nnz, sb[d].sum, sb[d].flag)
+    assert np.array_equal(a.dense(L.REC_CHAIN, d), b.dense(L.REC_CHAIN, d))
+a.close(); b.close(); model.close()
+print('DEVICE_EXCHANGE_OK', int(g['off'][-1]))
+'''
+
+
+def test_device_resident_kernel_exchange_feeds_the_chain_bitwise():
+    '''`parallel.prob_mass_sharded_device` keeps the day kernels on the device from the
+    builder to the chain (ps_model_export_device -> RCCL all_gather -> ps_chain_set_kernels_device /
+    ps_solver_set_state_device).  World size 1 here (the exchange across ranks is the gloo test's part):
+    the chain fed that way equals the chain fed by the model hand-over, bit for bit, and the exported
+    triplets are the ones `fetch` returns.  Runs in a process of its own that imports torch FIRST, the way
+    a torch.distributed driver does: torch's wheel brings its own HIP runtime, and a process that has
+    already initialised the system one through libparasitoid_hip.so finds no device through torch's.'''
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, '-c', _DEVICE_EXCHANGE, root], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert p.returncode == 0 and 'DEVICE_EXCHANGE_OK' in p.stdout, p.stderr[-3000:]

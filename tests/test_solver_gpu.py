@@ -439,7 +439,7 @@ def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
     trace, modelsol = {}, [first]
     OC.get_solutions(modelsol, pmfs, list(range(nd)), nd, N, ms, trace=trace)
     s = hip_lib.HipSolve(first, ms, mode='auto', chain_only=True)
-    for rep in range(2):                      # second run: the hint path starts where the first did
+    for rep in range(3):                      # second run: the hint path starts where the first did; third: route hints
         if rep:
             s.set_state(first)
         s.set_kernels(pmfs[1:])
@@ -468,7 +468,7 @@ def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
             s = hip_lib.HipSolve(state, [K, K], mode='auto', chain_only=True)
             s.set_kernels(kernels)
         routes = []
-        for rep in range(2):
+        for rep in range(3):                   # the third run also follows the hints of the second (narrow helper)
             s.set_state(state)
             s.run_chain(renorm=True)
             st = s.chain_stats(0, nd)
