@@ -138,6 +138,86 @@ __device__ __forceinline__ double pm_bvu_low_phi(const BvuRule& R, double h, dou
   return bvn * R.asr / (2 * TWOPI) + ph * pk;
 }
 
+// ... with the number of Gauss-Legendre node pairs a compile-time constant, and the 2 LG exponentials of
+// a corner evaluated SIDE BY SIDE.  The run-time-length loop above re-loads the rule's constants from
+// the kernel arguments every iteration (a scalar wait each time) and leaves every wave on one
+// 17-operation dependent chain per exponential: an in-order wave sits out each link, and four waves
+// per SIMD do not cover it (VALU busy 42 %).  Here the device library's exp() -- reduction by
+// ln 2 in two parts, degree-11 polynomial, ldexp, the two range clamps; constants and operation order
+// read off the compiler's own expansion -- is written out stage by stage over all 2 LG arguments, so
+// consecutive instructions of a wave are independent.  Same operations on the same operands, same
+// order of the weighted additions: bit-identical to pm_bvu_low_phi
+// (tests/test_model_gpu.py::test_unrolled_pair_masses_are_bit_identical).
+template <int M>
+__device__ __forceinline__ void pm_exp_many(double (&x)[M]) {
+  const double LOG2E = __longlong_as_double(0x3ff71547652b82feLL);
+  const double NLN2H = __longlong_as_double((long long)0xbfe62e42fefa39efULL);
+  const double NLN2L = __longlong_as_double((long long)0xbc7abc9e3b39803fULL);
+  const double C[10] = {__longlong_as_double(0x3e5ade156a5dcb37LL), __longlong_as_double(0x3e928af3fca7ab0cLL),
+                        __longlong_as_double(0x3ec71dee623fde64LL), __longlong_as_double(0x3efa01997c89e6b0LL),
+                        __longlong_as_double(0x3f2a01a014761f6eLL), __longlong_as_double(0x3f56c16c1852b7b0LL),
+                        __longlong_as_double(0x3f81111111122322LL), __longlong_as_double(0x3fa55555555502a1LL),
+                        __longlong_as_double(0x3fc5555555555511LL), __longlong_as_double(0x3fe000000000000bLL)};
+  double n[M], r[M], p[M];
+  // the scheduling barriers keep the stages apart: left alone, the machine scheduler strings the M chains
+  // back together one after the other to save registers (seen in the ISA), which is the dependent-chain
+  // stall this function exists to remove
+#define PM_STAGE(stmt)                \
+  _Pragma("unroll") for (int i = 0; i < M; ++i) { stmt; } \
+  __builtin_amdgcn_sched_barrier(0)
+  PM_STAGE(n[i] = rint(x[i] * LOG2E));
+  PM_STAGE(r[i] = __builtin_fma(NLN2H, n[i], x[i]));
+  PM_STAGE(r[i] = __builtin_fma(NLN2L, n[i], r[i]));
+  PM_STAGE(p[i] = __builtin_fma(C[0], r[i], C[1]));
+#pragma unroll
+  for (int c = 2; c < 10; ++c) {
+    PM_STAGE(p[i] = __builtin_fma(r[i], p[i], C[c]));
+  }
+  PM_STAGE(p[i] = __builtin_fma(r[i], p[i], 1.0));
+  PM_STAGE(p[i] = __builtin_fma(r[i], p[i], 1.0));
+#undef PM_STAGE
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    // (the library's other clamp, x > 1024 -> inf, cannot fire: the BVU exponents are <= 0 up to round-off)
+    const double v = ldexp(p[i], (int)n[i]);
+    x[i] = x[i] < -1075.0 ? 0.0 : v;
+  }
+}
+
+template <int LG>
+__device__ __forceinline__ double pm_bvu_low_phi_t(const BvuRule& R, double h, double k, double ph, double pk) {
+  const double TWOPI = 6.283185307179586;
+  const double hk = h * k;
+  const double hs = (h * h + k * k) / 2;
+  double e[2 * LG];
+#pragma unroll
+  for (int i = 0; i < LG; ++i) {
+    e[2 * i] = (R.sn1[i] * hk - hs) * R.iv1[i];
+    e[2 * i + 1] = (R.sn2[i] * hk - hs) * R.iv2[i];
+  }
+  if (LG <= 3) {
+    pm_exp_many<2 * LG>(e);
+  } else {   // six chains at a time: twelve side by side do not fit the registers of three waves per SIMD
+    static_assert(LG <= 3 || LG % 3 == 0, "groups of three node pairs");
+#pragma unroll
+    for (int g0 = 0; g0 < 2 * LG; g0 += 6) {
+      double t[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) t[i] = e[g0 + i];
+      pm_exp_many<6>(t);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) e[g0 + i] = t[i];
+    }
+  }
+  double bvn = 0.0;
+#pragma unroll
+  for (int i = 0; i < LG; ++i) {
+    bvn = bvn + R.w[i] * e[2 * i];
+    bvn = bvn + R.w[i] * e[2 * i + 1];
+  }
+  return bvn * R.asr / (2 * TWOPI) + ph * pk;
+}
+
 // rectangle probability of N(mu, S) on [xl,xu] x [yl,yu] as mvnun computes it
 __device__ __forceinline__ double pm_rect(const BvuRule& R, double sdx, double sdy, double mux,
                                           double muy, double xl, double xu, double yl, double yu) {
@@ -539,8 +619,9 @@ k_tile_fill(ModelParams mp, const PeriodInfo* __restrict__ pinfo, const DayInfo*
 // HIGH: the correlation takes Genz's |rho| >= 0.925 branch (uniform per batch; the host picks the
 // instance).  Keeping that branch out of the common instance is worth 50 registers: 165 -> ~110,
 // i.e. four resident waves per SIMD instead of three.
-template <bool HIGH>
-__global__ void __launch_bounds__(256, HIGH ? 2 : 4)   // common instance: 128 registers (2 spilled), four waves per SIMD
+// LG: the rule's number of node pairs as a compile-time constant (3 or 6; 0 = read it at run time)
+template <bool HIGH, int LG = 0>
+__global__ void __launch_bounds__(256, HIGH ? 2 : (LG >= 6 ? 2 : (LG > 0 ? 3 : 4)))   // run-time-count instance: 128 registers (2 spilled), four waves per SIMD; unrolled: 168, three
 k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int nt, long long npairs_, int seg,
               const long long* __restrict__ np_dev,   // != nullptr: the real pair count (npairs_ = capacity of the lists)
               const int* __restrict__ pair_t, const int* __restrict__ pair_tile, double* __restrict__ hm) {
@@ -596,10 +677,14 @@ k_pair_masses(ModelParams mp, const PeriodInfo* __restrict__ pinfo, int d0, int 
       s_py[g][b] = pm_phi(-k);
     }
     PM_WAVE_LDS_SYNC();
+    // idx / na by multiplication: na <= 17 and idx < 289, where (idx * ceil(2^16 / na)) >> 16 is exact
+    const unsigned na_magic = (65536u + (unsigned)na - 1u) / (unsigned)na;   // wave-uniform
     for (int idx = lane; idx < na * nb; idx += 64) {
-      const int b = b0 + idx / na, a = a0 + idx % na;
-      s_b[g][b * (PM_TS + 1) + a] = HIGH ? pm_bvu(mp.rule, s_hx[g][a], s_ky[g][b])
-                                         : pm_bvu_low_phi(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
+      const int qb = (int)(((unsigned)idx * na_magic) >> 16);
+      const int b = b0 + qb, a = a0 + (idx - qb * na);
+      if (HIGH) s_b[g][b * (PM_TS + 1) + a] = pm_bvu(mp.rule, s_hx[g][a], s_ky[g][b]);
+      else if (LG > 0) s_b[g][b * (PM_TS + 1) + a] = pm_bvu_low_phi_t<(LG > 0 ? LG : 1)>(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
+      else s_b[g][b * (PM_TS + 1) + a] = pm_bvu_low_phi(mp.rule, s_hx[g][a], s_ky[g][b], s_px[g][a], s_py[g][b]);
     }
     PM_WAVE_LDS_SYNC();
 #pragma unroll

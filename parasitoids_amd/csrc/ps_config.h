@@ -71,7 +71,8 @@
   X("PS_AUTO_WINDOW", auto_window, 4, INT, R)                                                       \
   /* prob_mass (ps_model handles) */                                                                \
   X("PS_PM_SEG", pm_seg, 8, INT, R)                                                                 \
-  X("PS_PM_SYNC", pm_sync, 0, FLAG, R)
+  X("PS_PM_SYNC", pm_sync, 0, FLAG, R)                                                              \
+  X("PS_PM_NO_UNROLL", pm_no_unroll, 0, FLAG, R)
 
 struct ps_config {
 #define PS_CFG_FIELD_FLAG int

@@ -153,6 +153,21 @@ extern "C" int ps_model_set_wind(ps_model* m, const double* wind, const int32_t*
   return PS_OK;
 }
 
+// the pair stage: the instance for the rule's branch and number of Gauss-Legendre node pairs
+// (|rho| < 0.3: 3, < 0.75: 6 -- compile-time constants, see pm_bvu_low_phi_t; 10 and the |rho| >= 0.925
+// branch read the count at run time)
+static void launch_pair_masses(ps_model* m, const ModelParams& mp, unsigned blocks, hipStream_t st, int d0, int nt,
+                               long long np, int seg, const long long* np_dev) {
+#define PS_PM_LAUNCH(...) \
+  hipLaunchKernelGGL((k_pair_masses<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg, np_dev, \
+                     m->pair_t.p, m->pair_tile.p, m->hm.p)
+  if (mp.rule.high) PS_PM_LAUNCH(true, 0);
+  else if (mp.rule.lg == 3 && !m->cfg.pm_no_unroll) PS_PM_LAUNCH(false, 3);
+  else if (mp.rule.lg == 6 && !m->cfg.pm_no_unroll) PS_PM_LAUNCH(false, 6);
+  else PS_PM_LAUNCH(false, 0);
+#undef PS_PM_LAUNCH
+}
+
 static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const double* start_time,
                           const double* hparams, const double* Dparams, const double* Dlparams,
                           double mu_r, int n_periods, double rad_dist, int rad_res,
@@ -262,12 +277,7 @@ static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const dou
                          m->toff.p, 0, 0LL, cap, m->pair_t.p, m->pair_tile.p);
       PS_HIP(hipGetLastError());
       const long long nseg = (cap + seg - 1) / seg;
-      if (mp.rule.high)
-        hipLaunchKernelGGL(k_pair_masses<true>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, 0, nt, cap, seg,
-                           m->np_dev.p, m->pair_t.p, m->pair_tile.p, m->hm.p);
-      else
-        hipLaunchKernelGGL(k_pair_masses<false>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, 0, nt, cap, seg,
-                           m->np_dev.p, m->pair_t.p, m->pair_tile.p, m->hm.p);
+      launch_pair_masses(m, mp, (unsigned)((nseg + 3) / 4), st, 0, nt, cap, seg, m->np_dev.p);
       PS_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_tile_accumulate, dim3(nt, nt, nd), dim3(PM_CELLS), 0, st, mp, m->tcnt.p, m->toff.p, 0,
                          0LL, seg, cap, m->hm.p, m->pmf.p);
@@ -299,12 +309,7 @@ static int prob_mass_impl(ps_model* m, int nd, const int32_t* day_idx, const dou
         PS_HIP(hipGetLastError());
         // periods per record (PS_PM_SEG; 1 = one record per (tile, period) pair: sequential-loop sums)
         const long long nseg = (np + seg - 1) / seg;
-        if (mp.rule.high)
-          hipLaunchKernelGGL(k_pair_masses<true>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg,
-                             (const long long*)nullptr, m->pair_t.p, m->pair_tile.p, m->hm.p);
-        else
-          hipLaunchKernelGGL(k_pair_masses<false>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, mp, m->pinfo.p, d0, nt, np, seg,
-                             (const long long*)nullptr, m->pair_t.p, m->pair_tile.p, m->hm.p);
+        launch_pair_masses(m, mp, (unsigned)((nseg + 3) / 4), st, d0, nt, np, seg, nullptr);
         PS_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_tile_accumulate, dim3(nt, nt, d1 - d0), dim3(PM_CELLS), 0, st, mp, m->tcnt.p, m->toff.p, d0,
                            base, seg, np, m->hm.p, m->pmf.p);

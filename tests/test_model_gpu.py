@@ -263,3 +263,25 @@ def test_prob_mass_day_does_not_depend_on_its_batch_beyond_round_off(PM, kalbar)
             assert np.array_equal(alone.data, batched.data)
         else:
             assert np.abs(alone.data - batched.data).max() < 1e-15
+
+
+def test_unrolled_pair_masses_are_bit_identical(PM, kalbar):
+    '''k_pair_masses<false, 3 / 6>: the Gauss-Legendre node count as a compile-time constant and the
+    device library's exp() written out stage by stage over the 6 / 12 exponentials of a corner
+    (pm_exp_many: same constants, same operations, same order) -- against the run-time-count instance
+    that calls exp() (PS_PM_NO_UNROLL): identical kernels bit for bit, for |rho| < 0.3 (3 node pairs)
+    and 0.3 <= |rho| < 0.75 (6).'''
+    wd, days = kalbar
+    for rho in (0.253, -0.1, 0.5, -0.7):
+        out = []
+        for no_unroll in (0, 1):
+            m = PM.WindModel(wd)
+            m.set_option('PS_PM_NO_UNROLL', no_unroll)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore', RuntimeWarning)
+                m.build(days[:3], HP, (DP[0], DP[1], rho), DLP, MU_R, NPER, 10000.0, 128)
+                out.append([m.fetch(i) for i in range(3)])
+            m.close()
+        for a, b in zip(*out):
+            assert a.shape == b.shape and a.nnz == b.nnz
+            assert np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col) and np.array_equal(a.data, b.data)
