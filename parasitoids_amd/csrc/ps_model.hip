@@ -154,8 +154,14 @@ extern "C" int ps_model_set_wind(ps_model* m, const double* wind, const int32_t*
 }
 
 // the pair stage: the instance for the rule's branch and number of Gauss-Legendre node pairs
-// (|rho| < 0.3: 3, < 0.75: 6 -- compile-time constants, see pm_bvu_low_phi_t; 10 and the |rho| >= 0.925
-// branch read the count at run time)
+// (|rho| < 0.3: 3 node pairs as a compile-time constant, see pm_bvu_low_phi_t; 6, 10 and the
+// |rho| >= 0.925 branch read the count at run time).  PMC (profiles/r04_prob_mass_pair_kernel_pmc.txt): the
+// kernel issues 4.06e8 wave-instructions per 18-day batch at R = 400, nearly all of them fp64 at 4 cycles
+// each on a SIMD's 16 fp64 lanes -- 1.59e6 cycles per SIMD of the 1.7e6 the launch lasts: it is at the
+// vector ISSUE limit (SQ_ACTIVE_INST_VALU / SQ_BUSY 0.93), not latency-bound; the unrolled instance halves
+// the scalar traffic and the waiting (SQ_WAIT_ANY 3.1e8 -> 1.8e8) and gains 1 %, because waiting was not
+// what the time went to.  Average active lanes 71 % (partly filled corner iterations, the erfc phase on
+// half a wave).
 static void launch_pair_masses(ps_model* m, const ModelParams& mp, unsigned blocks, hipStream_t st, int d0, int nt,
                                long long np, int seg, const long long* np_dev) {
 #define PS_PM_LAUNCH(...) \
@@ -163,8 +169,7 @@ static void launch_pair_masses(ps_model* m, const ModelParams& mp, unsigned bloc
                      m->pair_t.p, m->pair_tile.p, m->hm.p)
   if (mp.rule.high) PS_PM_LAUNCH(true, 0);
   else if (mp.rule.lg == 3 && !m->cfg.pm_no_unroll) PS_PM_LAUNCH(false, 3);
-  else if (mp.rule.lg == 6 && !m->cfg.pm_no_unroll) PS_PM_LAUNCH(false, 6);
-  else PS_PM_LAUNCH(false, 0);
+  else PS_PM_LAUNCH(false, 0);   // (six node pairs unrolled: measured slower, 1.69 against 1.65 ms per 18-day batch)
 #undef PS_PM_LAUNCH
 }
 

@@ -266,11 +266,11 @@ def test_prob_mass_day_does_not_depend_on_its_batch_beyond_round_off(PM, kalbar)
 
 
 def test_unrolled_pair_masses_are_bit_identical(PM, kalbar):
-    '''k_pair_masses<false, 3 / 6>: the Gauss-Legendre node count as a compile-time constant and the
-    device library's exp() written out stage by stage over the 6 / 12 exponentials of a corner
+    '''k_pair_masses<false, 3>: the Gauss-Legendre node count as a compile-time constant and the
+    device library's exp() written out stage by stage over the 6 exponentials of a corner
     (pm_exp_many: same constants, same operations, same order) -- against the run-time-count instance
-    that calls exp() (PS_PM_NO_UNROLL): identical kernels bit for bit, for |rho| < 0.3 (3 node pairs)
-    and 0.3 <= |rho| < 0.75 (6).'''
+    that calls exp() (PS_PM_NO_UNROLL): identical kernels bit for bit for |rho| < 0.3 (3 node pairs);
+    0.3 <= |rho| < 0.75 (6 pairs) takes the run-time-count instance either way.'''
     wd, days = kalbar
     for rho in (0.253, -0.1, 0.5, -0.7):
         out = []
