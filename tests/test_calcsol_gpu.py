@@ -213,13 +213,14 @@ def test_baseline_config2_population_model_1024(golden_dir, rad_dist):
         assert modelsol[-1].sum() > 0.999 * p.r_number
 
 
-@pytest.mark.parametrize('mode', ['fast', 'auto'])
+@pytest.mark.parametrize('mode', ['fast', 'exact', 'auto'])
 def test_multi_day_release_on_the_chain_api(golden_dir, mode):
     """get_populations with r_dur = 5 (the reference's default Carnarvon preset, Run.py:118) through
     ps_chain_run_release -- day kernels and release-day filters uploaded once, every day after the release
     enqueued without a host round trip (CalcSol.py:296-323, cuda_lib.py:145-221) -- against the oracle's
     get_populations on the same kernels, at a domain where the flag FIRES in the cohort and in the
-    back-solves (10 km, R = 128).  'fast': the chain route, fast-torus tolerance.  'auto': the fast torus
+    back-solves (10 km, R = 128).  'fast': the chain route, fast-torus tolerance.  'exact': the chain
+    route on the reference's own torus (tiled pipeline), 1e-7.  'auto': the fast torus
     cannot certify this run (dust outside the domain), the exact per-call route takes over: 1e-7 on
     populations up to 8000 per cohort (1e-11 relative).  The flag-free 40 km run of G8
     (test_run_pop_model_carnarvon_rdur5) is the certified 'auto' chain route against the reference."""
@@ -235,7 +236,7 @@ def test_multi_day_release_on_the_chain_api(golden_dir, mode):
     finally:
         globalvars.fft_mode = old
     assert ndays == 12 and len(modelsol) == 12
-    assert CalcSol.last_release_route == ('chain' if mode == 'fast' else 'per-call')
+    assert CalcSol.last_release_route == ('per-call' if mode == 'auto' else 'chain')
     wind_data, days2 = PM.get_wind_data(*p.get_wind_params())
     starts = [p.r_start] + [None] * (ndays - 1)
     pmf_list = PM.prob_mass_batch(days2[:ndays], wind_data, *p.get_model_params(), start_times=starts)
@@ -246,7 +247,7 @@ def test_multi_day_release_on_the_chain_api(golden_dir, mode):
     trace = {}
     ref = OC.get_populations(r_spread, pmf_list, days2, ndays, 257, max_shape, p.r_dur, p.r_number,
                              p.r_mthd(), trace=trace)
-    tol = 1e-7 if mode == 'auto' else 5e-8 * p.r_number       # fast torus: <= 1e-8 per un-flagged field
+    tol = 5e-8 * p.r_number if mode == 'fast' else 1e-7       # fast torus: <= 1e-8 per un-flagged field
     for i, (a, b) in enumerate(zip(modelsol, ref)):
         d = abs(a.tocsr() - b.tocsr())
         assert (d.max() if d.nnz else 0.0) < tol, (mode, i)
