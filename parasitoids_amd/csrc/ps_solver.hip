@@ -2432,12 +2432,8 @@ extern "C" int ps_chain_run_release(ps_solver* s, int first, int count, double n
   PS_TRY(ensure_spectrum(s));
   // transforms: the run's day kernels and the filters side by side in one buffer, ONE format
   // (direct_chunk = 0: no direct-sum route, the two halves of the buffer are consumed alike)
-  if (count > s->chunk_days) return ps_fail(PS_ERR_UNSUPPORTED, "run_release: %d days exceed one chunk of kernel spectra (%d)", count, s->chunk_days);
-  const int total = count + nuse;
-  if (count > 0) PS_TRY(transform_kernels(s, first, count, 0, total, 0));
-  if (nuse > 0) PS_TRY(transform_kernels(s, ndays, nuse, count, total, 0));
-  s->bhat_first = -1;                        // the buffer is not a plain run of days: nothing to reuse
-  s->bhat_count = 0;
+  // (long runs go chunk by chunk like ps_chain_run; the filters are transformed again with every chunk)
+  const int cdays = std::max(1, s->chunk_days - nuse);
   // the weighted sum's pointer / weight tables are the same every day
   {
     std::vector<const double*> ptrs(per);
@@ -2450,17 +2446,27 @@ extern "C" int ps_chain_run_release(ps_solver* s, int first, int count, double n
     PS_HIP(hipStreamSynchronize(s->stream));   // host temporaries
   }
   const int64_t tot = (int64_t)s->N * s->N;
+  int c0 = 0, cn = 0;                        // days [c0, c0 + cn) of the run have their spectra in the buffer
   for (int u = 0; u < units; ++u) {
     const int d = first + u, sl = slot0 + u * per;
+    if (u >= c0 + cn) {
+      c0 = u;
+      cn = count > 0 ? std::min(cdays, count - c0) : 0;
+      if (cn > 0) PS_TRY(transform_kernels(s, first + c0, cn, 0, cn + nuse, 0));
+      if (nuse > 0) PS_TRY(transform_kernels(s, ndays, nuse, cn, cn + nuse, 0));
+      s->bhat_first = -1;                    // the buffer is not a plain run of days: nothing to reuse
+      s->bhat_count = 0;
+      if (count == 0) cn = 1;                // the single back-solve unit
+    }
     if (count > 0) {
-      const cplx* B = s->Bhat.p + (size_t)u * spec;
+      const cplx* B = s->Bhat.p + (size_t)(u - c0) * spec;
       double* rec = s->recs[PS_REC_STATE][1];
       PS_TRY(conv_inv(s, B, s->Ahat.p, 1, rec, sl + nuse, negval, 1.0, s->krange.p + 2 * d));
       PS_TRY(refft_if_flag(s, rec, s->Ahat.p, sl + nuse));
     }
     if (nuse > 0) PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
     for (int i = nuse - 1; i >= 0; --i) {
-      const cplx* F = s->Bhat.p + (size_t)(count + i) * spec;
+      const cplx* F = s->Bhat.p + (size_t)((count > 0 ? cn : 0) + i) * spec;
       double* rec = s->recs[PS_REC_BACK][i];
       PS_TRY(conv_inv(s, F, s->Chat.p, 1, rec, sl + i, negval, 1.0, s->krange.p + 2 * (ndays + i)));
       PS_TRY(refft_if_flag(s, rec, s->Chat.p, sl + i));

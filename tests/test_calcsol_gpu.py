@@ -274,3 +274,22 @@ def test_multi_day_release_certified_chain_route(golden, golden_dir):
         d = abs(x.tocsr() - y.tocsr())
         assert (d.max() if d.nnz else 0.0) < 1e-8, i
         assert_summary(g, 'car_sum%d' % i, x, g['car_pos'], rtol=1e-9, atol=1e-7, nnz_slack=4)
+
+
+def test_multi_day_release_runs_chunk_by_chunk(golden_dir, monkeypatch):
+    """ps_chain_run_release keeps the spectra of a chunk of day kernels plus the filters at a time; a run
+    longer than a chunk (here PS_CHUNK_DAYS = 6: two days + four filters per chunk) gives the same
+    populations bit for bit as the run whose 7 days fit one chunk."""
+    from parasitoids_amd import CalcSol, globalvars
+    Run, p = _params(golden_dir, '--carnarvon', '--pop', 'ndays=12', 'domain_info=(10000.0,128)')
+    old = globalvars.fft_mode
+    globalvars.fft_mode = 'fast'
+    try:
+        a, _, _, _ = Run.run_model(p, verbose=False)
+        monkeypatch.setenv('PS_CHUNK_DAYS', '6')
+        b, _, _, _ = Run.run_model(p, verbose=False)
+    finally:
+        globalvars.fft_mode = old
+    assert CalcSol.last_release_route == 'chain' and len(a) == len(b) == 12
+    for x, y in zip(a, b):
+        assert (x != y).nnz == 0
