@@ -4,6 +4,7 @@
 #pragma once
 #include "fft_kernels.h"
 #include "fft_rs.h"
+#include <type_traits>
 
 
 // ------------------------------------------------------------ inverse rows
@@ -566,6 +567,336 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
   if (pend && finalizer) finalize(pend_b, pend_ra, red + (par ^ 1) * 5 * NW);
 }
 
+
+
+// ------------------------------------------------------------ inverse rows, persistent, TWO ROLES in anti-phase
+// k_row_inv_rsp runs ONE row pair per workgroup and CU at a time: its six waves sit 2-2-1-1 on the SIMDs
+// (324 / 288 / 288 butterflies per stage at 5184 are 5.06 / 4.5 / 4.5 waves), every phase of a pair --
+// first-stage reads, three stages with eight exchange barriers, scaling / threshold / statistics / stores --
+// waits for the one before, and only the HBM traffic (prefetch by the load unit, stores) overlaps anything:
+// 11.4 us per pair where the transform alone takes 5.9 and the memory side about 6.
+// Here a workgroup has two roles of NTHR threads each, every role walking its own row pairs, half a period
+// apart: while role X transforms its pair (the "T" half-period), role Y finishes the pair it transformed
+// before -- scale, threshold statistics, stores -- and starts the copy of its next pair's two rows HBM -> LDS
+// (the "S" half-period); then they swap.  The staging area is shared in time: the T role has read its rows
+// out of it before the S role's copy starts, and that copy has the whole transform of the other role to
+// land.  Same LDS as k_row_inv_rsp (exchange buffer + two staged rows), twelve waves 3-3-3-3.
+// Barriers are shared (`s_barrier` counts arrivals per workgroup, whatever the program counter): a
+// half-period is nine of them in either kind, and each role runs its own straight-line loop -- as ONE loop
+// body with a wave-uniform branch between the barriers the register allocator, which is not
+// path-sensitive, kept one role's values alive through the other role's code.
+// Same loads, same transform code (rs_stage / bfly), same epilogue arithmetic in the same order as
+// k_row_inv_rsp / k_row_inv_rs: bit-identical records, statistics and pad maxima
+// (tests/test_solver_gpu.py::test_persistent_row_kernel_is_bit_identical).
+template <int R1, int R2, int R3>
+struct Rs2Lds {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  static constexpr int NW = S::NTHR / 64;
+  static constexpr int RED = 8 * NW;                      // per role: 5 NW partials, NW energy sums (+ slack)
+  static constexpr int HS = (S::L / 2 + 1 + 63) & ~63;    // a staged row: whole 64-element chunks
+  static constexpr size_t bytes = (size_t)(Y::XW + 2 * RED) * sizeof(double) + 2 * (size_t)HS * sizeof(cplx);
+  // two roles of NTHR threads in one workgroup; radices above 18 do not fit the 168 registers of 12 waves
+  static constexpr bool ok = 2 * S::NTHR <= 1024 && S::RMAX <= 18 && bytes <= (size_t)160 * 1024;
+};
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_row_inv_rs2(RowInvArgs a, int npairs, int units) {
+  using S = Rs<R1, R2, R3>;
+  using Y = RsInvLds<R1, R2, R3>;
+  using Z = Rs2Lds<R1, R2, R3>;
+  constexpr int L = S::L;
+  constexpr int NW = S::NTHR / 64;
+  constexpr int NCH = Z::HS / 64;              // 1 KB chunks per staged row
+  constexpr int H = L / 2 + 1;
+  double* ex = reinterpret_cast<double*>(ps_lds_raw);
+  // (the scalar copy tells the compiler what it cannot see: everything derived from the role -- the unit a
+  // role holds, its rows, the domain tests of the epilogue -- is uniform and lives in scalar registers)
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / S::NTHR);
+  const int j0 = threadIdx.x - role * S::NTHR, lane = j0 & 63, wave = __builtin_amdgcn_readfirstlane(j0 >> 6);
+  double* red = ex + Y::XW + role * Z::RED;                 // this role's 5 NW partials
+  double* ered = red + 5 * NW;                              // ... and NW energy sums
+  cplx* stA = reinterpret_cast<cplx*>(ex + Y::XW + 2 * Z::RED);
+  cplx* stB = stA + Z::HS;
+  const FftProg& P = a.prog;
+  const cplx w2c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j0));
+  const cplx w3c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j0 < S::T3 ? S::tw3(j0) : 0);
+  const int G2 = 2 * (int)gridDim.x;
+
+  // a role's units: (2 b + role), + 2 G, ...; pad-only pairs of a day the column pass found quiet are no
+  // units at all (see k_row_inv_rsp)
+  auto next_unit = [&](int v) {   // uniform
+    while (v < units && a.pad_quiet) {
+      const int vb = v / npairs, vp = v - vb * npairs;
+      if (2 * vp < a.N || !a.pad_quiet[vb]) break;
+      v += G2;
+    }
+    return v;
+  };
+  auto count_units = [&](int r) {
+    int n = 0;
+    for (int v = next_unit(2 * (int)blockIdx.x + r); v < units; v = next_unit(v + G2)) ++n;
+    return n;
+  };
+  // half-periods of the workgroup: role 0 transforms in the even ones (its last epilogue in 2 n0 - 1), role 1
+  // in the odd ones (first copy in 0, last epilogue in 2 n1): both roles run the same number of barriers
+  const int n0 = count_units(0), n1 = count_units(1);
+  const int HP = max(2 * n0, n1 > 0 ? 2 * n1 + 1 : 0);
+
+  cplx x[S::RMAX];
+  int cur = next_unit(2 * (int)blockIdx.x + role);          // the unit this role is fetching / holds
+  bool loaded = false;        // the copy of unit cur's rows is on its way to (or in) the staging area
+  bool done = false;          // x holds unit cur's transformed rows: the epilogue is due
+
+  // rows of unit u -> staging; every wave of the role copies the chunks c = wave, wave + NW, ... (row A, then B)
+  auto prefetch = [&](int u) {
+    const int b = u / npairs, pair = u - b * npairs;
+    const cplx* src = a.src + (int64_t)b * a.src_bstride;
+    const int ra = 2 * pair, rb = (ra + 1 < a.P) ? ra + 1 : ra;
+    const cplx* pa = src + (int64_t)ra * a.ld;
+    const cplx* pb = src + (int64_t)rb * a.ld;
+    // (opaque lane: the per-lane element indices are loop-invariant, and at this kernel's register limit the
+    // compiler kept them in scratch -- a scratch reload and a wait for ALL outstanding copies in front of
+    // every copy instruction, i.e. one copy at a time)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int t = 0; t < (2 * NCH + NW - 1) / NW; ++t) {
+      const int c = wave + t * NW;             // wave-uniform
+      if (c < 2 * NCH) {
+        const bool isb = c >= NCH;
+        const int cc = isb ? c - NCH : c;
+        int k = cc * 64 + ln;
+        k = k < H ? k : H - 1;                 // the last chunk: stay inside the row
+        const cplx* g = (isb ? pb : pa) + k;
+        cplx* d = (isb ? stB : stA) + cc * 64; // + lane * 16 B by the instruction
+        __builtin_amdgcn_global_load_lds(g, (ps_lds_ptr)d, 16, 0, 0);
+      }
+    }
+  };
+
+  // the epilogue of a finished pair (as k_row_inv_rsp) runs in three pieces, in the shadow of the other
+  // role's three butterfly intervals; its sums travel in registers, its statistics are written by one lane
+  // in this role's next transform half-period (`pend`)
+  int eb = 0, era = 0;          // day and first row of the pair whose epilogue is running
+  double e_sa = 0.0, e_sb = 0.0, e_pmax = 0.0;
+  int e_ca = 0, e_cb = 0;
+  bool pend = false;            // partials of a finished epilogue wait in `red`
+  int pend_b = 0, pend_ra = 0;
+  auto epi_piece = [&](int j, auto q0c, auto q1c) {
+    constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
+    const int ra = era, rb = era + 1;
+    double* rec = a.nrec > 0 ? a.rec_multi[eb] : a.rec + (int64_t)eb * a.rec_bstride;
+    if (j < S::T3) {
+      double* reca = rec + (int64_t)ra * a.N;
+      double* recb = rec + (int64_t)rb * a.N;
+      const bool dom_a = ra < a.N, dom_b = rb < a.N;
+      const unsigned uj = (unsigned)j, uN = (unsigned)a.N;
+      const bool dom_ab = dom_a && dom_b;
+      const bool hb = rb < a.P;
+#pragma unroll
+      for (int q = Q0; q < Q1; ++q) {
+        const unsigned i = uj + (unsigned)(q * S::T3);
+        const double va = x[q].x * a.scale, vb = x[q].y * a.scale;
+        const double ta = va * a.stat_scale, tb = vb * a.stat_scale;
+        if (dom_ab && (unsigned)((q + 1) * S::T3) <= uN) {
+          reca[i] = va;
+          recb[i] = vb;
+          const bool ka = !(ta < a.negval), kb = !(tb < a.negval);
+          e_sa += ka ? ta : 0.0;
+          e_sb += kb ? tb : 0.0;
+          e_ca += __popcll(__ballot(ka));
+          e_cb += __popcll(__ballot(kb));
+        } else {
+          const bool in = i < uN;
+          const bool ina = in && dom_a, inb = in && dom_b;
+          const bool ka = ina && !(ta < a.negval), kb = inb && !(tb < a.negval);
+          e_sa += ka ? ta : 0.0;
+          e_sb += kb ? tb : 0.0;
+          e_ca += __popcll(__ballot(ka));
+          e_cb += __popcll(__ballot(kb));
+          e_pmax = fmax(e_pmax, ina ? 0.0 : va);
+          e_pmax = fmax(e_pmax, (inb || !hb) ? 0.0 : vb);
+          if (ina) reca[i] = va;
+          if (inb) recb[i] = vb;
+        }
+      }
+    }
+  };
+  auto finalize = [&]() {       // one lane: the statistics of the pair whose partials are in `red`
+    double ta = 0, tb = 0, na = 0, nbb = 0, m = 0;
+    for (int w = 0; w < NW; ++w) {
+      ta += red[w * 4 + 0];
+      tb += red[w * 4 + 1];
+      na += red[w * 4 + 2];
+      nbb += red[w * 4 + 3];
+      m = fmax(m, red[4 * NW + w]);
+    }
+    const int frb = pend_ra + 1;
+    double* rowsum = a.rowsum + (int64_t)pend_b * a.stat_bstride;
+    long long* rowcnt = a.rowcnt + (int64_t)pend_b * a.stat_bstride;
+    if (pend_ra < a.N) { rowsum[pend_ra] = ta; rowcnt[pend_ra] = (long long)na; }
+    if (frb < a.N) { rowsum[frb] = tb; rowcnt[frb] = (long long)nbb; }
+    unsigned long long* pm = a.padmax + pend_b;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m > a.pad_floor && bits > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(pm, bits);
+  };
+  // ---- the two kinds of half-period, nine barriers each
+  auto T_half = [&]() {
+    int j = j0;
+    cplx w2 = w2c, w3 = w3c;
+    asm volatile("" : "+v"(j), "+v"(w2.x), "+v"(w2.y), "+v"(w3.x), "+v"(w3.y));   // see k_row_inv_rsp
+    bool act = loaded;          // this role has a pair to transform
+    const int pair = cur % npairs;
+    const bool pad_only = 2 * pair >= a.N;
+    const bool hasb = 2 * pair + 1 < a.P;
+    // (this wave's chunks of the staged rows have landed: it waited for them in its S half-period, BEFORE it
+    // issued the last piece of its epilogue's stores -- a wait here would be a wait for those stores)
+    PS_BAR_LDS();                                           // B0: ... and everybody's (and the last epilogue's partials)
+    if (pend && j0 == S::NTHR - 1) finalize();
+    pend = false;
+    double energy = 0.0;
+    if (act && j < S::T1) {
+#pragma unroll
+      for (int q = 0; q < R1; ++q) {
+        const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);   // j + q T1 <= L/2
+        const int i = j + q * S::T1;
+        const int k = direct ? i : L - i;
+        const cplx A = stA[k];
+        cplx B = stB[k];
+        if (!hasb) B = make_double2(0.0, 0.0);
+        if (direct) energy += A.x * A.x + A.y * A.y + B.x * B.x + B.y * B.y;
+        x[q] = direct ? make_double2(A.x - B.y, A.y + B.x) : make_double2(A.x + B.y, B.x - A.y);
+      }
+    }
+    if (act && pad_only) {      // Parseval bound on the largest value of a pad-only pair, see k_row_inv
+      energy = ps_wave_sum(energy);
+      if (lane == 63) ered[wave] = energy;
+    }
+    PS_BAR_LDS();                                           // B1: staging free for the other role's copy
+    if (act && pad_only) {
+      double e = 0.0;
+      for (int w = 0; w < NW; ++w) e += ered[w];
+      if (sqrt(2.0 * (double)a.P * e) * a.scale < a.pad_floor) act = false;   // cannot raise the flag: skipped
+    }
+    if (act && j < S::T1) {
+      bfly<R1, PS_INV>(x);
+      rs_put<R1, 0>(ex, S::x1_w(j), 1, x);
+    }
+    PS_BAR_LDS();                                           // B2
+    if (act && j < S::T2) rs_get<R2, 0>(ex, S::x_r(j), S::X1_RS, x);
+    PS_BAR_LDS();                                           // B3
+    if (act && j < S::T1) rs_put<R1, 1>(ex, S::x1_w(j), 1, x);
+    PS_BAR_LDS();                                           // B4
+    if (act && j < S::T2) rs_get<R2, 1>(ex, S::x_r(j), S::X1_RS, x);
+    // (twiddle powers are formed here, not hoisted above the exchange where they would cost 36 registers)
+    asm volatile("" : "+v"(w2.x), "+v"(w2.y));
+    if (act && j < S::T2) rs_stage<R2, PS_INV>(x, w2, true);
+    PS_BAR_LDS();                                           // B5
+    if (act && j < S::T2) rs_put<R2, 0>(ex, S::x2_w(j), 17, x);
+    PS_BAR_LDS();                                           // B6
+    if (act && j < S::T3) rs_get<R3, 0>(ex, S::x_r(j), S::X2_RS, x);
+    PS_BAR_LDS();                                           // B7
+    if (act && j < S::T2) rs_put<R2, 1>(ex, S::x2_w(j), 17, x);
+    PS_BAR_LDS();                                           // B8
+    if (act && j < S::T3) rs_get<R3, 1>(ex, S::x_r(j), S::X2_RS, x);
+    asm volatile("" : "+v"(w3.x), "+v"(w3.y));
+    if (act && j < S::T3) rs_stage<R3, PS_INV>(x, w3, true);
+    // what this role does in its next half-period: the epilogue of this pair (or, skipped: the next pair)
+    if (loaded) {
+      loaded = false;
+      if (act) done = true;
+      else cur = next_unit(cur + G2);
+    }
+  };
+  // piece k of 6 of the epilogue: q in [k R3 / 6, (k + 1) R3 / 6)
+#define PS_EPI_PIECE(k) \
+  if (epi) epi_piece(j, std::integral_constant<int, ((k) * R3) / 6>(), std::integral_constant<int, (((k) + 1) * R3) / 6>())
+  auto S_half = [&]() {
+    int j = j0;
+    asm volatile("" : "+v"(j));
+    const bool epi = done;
+    if (epi) {
+      eb = cur / npairs;
+      era = 2 * (cur - eb * npairs);
+      e_sa = e_sb = e_pmax = 0.0;
+      e_ca = e_cb = 0;
+      done = false;
+      cur = next_unit(cur + G2);
+    }
+    PS_BAR_LDS();                                           // B0
+    PS_BAR_LDS();                                           // B1: the other role has read the staging area
+    loaded = false;
+    if (cur < units) {                                      // the next pair of this role: its copy has the whole
+      prefetch(cur);                                        // transform of the other role to land
+      loaded = true;
+    }
+    PS_BAR_LDS();                                           // B2
+    // the epilogue in six pieces, one per exchange interval of the other role's transform: a piece has to
+    // be shorter than the interval it hides in, or the transform waits for it at the next barrier
+    PS_EPI_PIECE(0);
+    PS_BAR_LDS();                                           // B3
+    PS_EPI_PIECE(1);
+    PS_BAR_LDS();                                           // B4
+    PS_EPI_PIECE(2);
+    PS_BAR_LDS();                                           // B5
+    PS_EPI_PIECE(3);
+    PS_BAR_LDS();                                           // B6
+    PS_EPI_PIECE(4);
+    PS_BAR_LDS();                                           // B7
+    PS_EPI_PIECE(5);
+    PS_BAR_LDS();                                           // B8
+    if (epi) {
+      const double sa = ps_wave_sum(e_sa), sb = ps_wave_sum(e_sb);
+      const int ca = __builtin_amdgcn_readfirstlane(e_ca), cb = __builtin_amdgcn_readfirstlane(e_cb);
+      const double pmax = ps_wave_max0(e_pmax);
+      if (lane == 63) {
+        red[wave * 4 + 0] = sa;
+        red[wave * 4 + 1] = sb;
+        red[wave * 4 + 2] = (double)ca;
+        red[wave * 4 + 3] = (double)cb;
+        red[4 * NW + wave] = pmax;
+      }
+      pend = true;
+      pend_b = eb;
+      pend_ra = era;
+    }
+    PS_WAIT_VM0();                                          // the copy issued behind B1 (and the stores, long issued)
+  };
+#undef PS_EPI_PIECE
+  auto idle_half = [&]() {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) PS_BAR_LDS();
+  };
+
+  // role 0 transforms in the even half-periods, role 1 in the odd ones; each role runs its own loop
+  if (role == 0) {
+    if (cur < units) {          // prologue: its first pair comes in here
+      prefetch(cur);
+      PS_WAIT_VM0();
+      loaded = true;
+    }
+    for (int k = 0; k < n0; ++k) {
+      T_half();
+      S_half();
+    }
+    for (int h = 2 * n0; h < HP; ++h) idle_half();
+  } else {
+    for (int k = 0; k < n1; ++k) {
+      S_half();
+      T_half();
+    }
+    int h = 2 * n1;
+    if (n1 > 0) {
+      S_half();
+      ++h;
+    }
+    for (; h < HP; ++h) idle_half();
+  }
+  PS_BAR_LDS();                                             // the last epilogue's partials
+  if (pend && j0 == S::NTHR - 1) finalize();
+}
 
 
 // ------------------------------------------------------------ forward rows

@@ -44,6 +44,7 @@
   /* routes (A/B legs of the bit-identity tests) */                                                 \
   X("PS_TINV", tinv, 0, INT, R)                                                                     \
   X("PS_RSP", rsp, -1, INT, R)                                                                      \
+  X("PS_ROW2", row2, -1, INT, R)                                                                    \
   X("PS_TPIPE", tpipe, -1, INT, R)                                                                  \
   X("PS_TPIPE_SPLIT", tpipe_split, 0, INT, R)                                                       \
   X("PS_NO_CONJ", no_conj, 0, FLAG, R)                                                              \

@@ -2,6 +2,7 @@
 // translation unit so that they compile in parallel with the rest of the library.
 #include "rs_cfg.h"
 #include "rs_launch.h"
+#include <algorithm>
 #include <cstdlib>
 
 bool rs_lookup(int L, int* r2, int* r3) {
@@ -40,6 +41,12 @@ int rs_rows_set_attrs() {
     if constexpr (Z::fits) {                                                                                 \
       auto kp = k_row_inv_rsp<16, A, B>;                                                                     \
       if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z::bytes) != hipSuccess) return -1; \
+    }                                                                                                        \
+    using Z2 = Rs2Lds<16, A, B>;                                                                             \
+    if constexpr (Z2::ok) {                                                                                  \
+      auto k2 = k_row_inv_rs2<16, A, B>;                                                                     \
+      if (Z2::bytes > 48 * 1024 &&                                                                           \
+          hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z2::bytes) != hipSuccess) return -1; \
     }                                                                                                        \
     if (C::LDSC1 > 48 * 1024) {                                                                              \
       auto kr = k_row_inv_fold<16, A, B>;                                                                    \
@@ -125,6 +132,16 @@ int rs_launch_row_inv(int r2, int r3, const RowInvArgs& a, int npairs, int batch
   if (r2 == A && r3 == B) {                                                                                  \
     using C = RsCfg<A, B>;                                                                                   \
     using Z = RsPLds<16, A, B>;                                                                              \
+    using Z2 = Rs2Lds<16, A, B>;                                                                             \
+    if constexpr (Z2::ok) {                                                                                  \
+      if (a.persistent == 2 && a.tstride == 0) {   /* two roles in anti-phase, one workgroup per CU */      \
+        const int units = npairs * batch;                                                                    \
+        const int wgs = std::min(device_cus(), (units + 1) / 2);                                             \
+        auto k2 = k_row_inv_rs2<16, A, B>;                                                                   \
+        hipLaunchKernelGGL(k2, dim3(wgs), dim3(2 * C::S::NTHR), Z2::bytes, st, a, npairs, units);            \
+        return 1;                                                                                            \
+      }                                                                                                      \
+    }                                                                                                        \
     if constexpr (Z::fits) {                                                                                 \
       if (a.persistent && a.tstride == 0) {                                                                  \
         const int units = npairs * batch;                                                                    \

@@ -476,6 +476,11 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   RowInvArgs a;
   a.pad_quiet = pad_quiet;
   a.persistent = (row_inv_persistent(s) && !(s->tpipe && s->tinv && !full_field)) ? 1 : 0;
+  // the two-role anti-phase kernel (k_row_inv_rs2) where the persistent one would run and the size has it
+  // (PS_ROW2: A/B knob; the launcher falls back to k_row_inv_rsp for the other sizes)
+  // Default (-1): from 4096 points on -- below, several one-role workgroups share a CU and do better
+  // (2688: 0.78 against 0.86 ms per chain); at 5184 the two roles take the 30-day launch from 2.67 to 2.54 ms.
+  if (a.persistent && (s->cfg.row2 > 0 || (s->cfg.row2 < 0 && s->Pf >= 4096))) a.persistent = 2;
   a.nrec = 0;
   for (int i = 0; i < PS_MAX_GROUP_DAYS; ++i) a.rec_multi[i] = nullptr;
   if (recs_multi) {

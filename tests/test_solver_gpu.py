@@ -487,7 +487,8 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
     HBM -> LDS, all days of a chained group in one launch) performs the transform and the epilogue
     of k_row_inv_rs on the same values in the same order: records, flags and statistics must be
     BIT-identical with PS_RSP=0 (one-shot kernel), PS_RSP=1 and PS_NO_ROW_BATCH=1 (one launch per
-    day) -- un-flagged chained groups (2, 4, 8 days) and a flagged chain (single days, pad rows
+    day), and with k_row_inv_rs2 (PS_ROW2=1: two roles per workgroup in anti-phase, the default from 4096
+    points on) -- un-flagged chained groups (2, 4, 8 days) and a flagged chain (single days, pad rows
     that raise the flag, the Parseval skip of quiet pad-only pairs)."""
     from parasitoids_amd import synthetic
     R, K, nd = 400, 401, 16
@@ -496,9 +497,11 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
         _, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=7, sigma=(6.0, 12.0), shift=10)
         state = sparse.coo_matrix(([1.0], ([start], [start])), shape=(N, N))
         runs = {}
-        for tag, env in (('oneshot', {'PS_RSP': '0'}), ('persistent', {'PS_RSP': '1'}),
-                         ('per_day', {'PS_RSP': '1', 'PS_NO_ROW_BATCH': '1'})):
-            for k in ('PS_RSP', 'PS_NO_ROW_BATCH'):
+        for tag, env in (('oneshot', {'PS_RSP': '0'}), ('persistent', {'PS_RSP': '1', 'PS_ROW2': '0'}),
+                         ('per_day', {'PS_RSP': '1', 'PS_NO_ROW_BATCH': '1', 'PS_ROW2': '0'}),
+                         ('two_role', {'PS_RSP': '1', 'PS_ROW2': '1'}),          # k_row_inv_rs2: two roles in anti-phase
+                         ('two_role_per_day', {'PS_RSP': '1', 'PS_ROW2': '1', 'PS_NO_ROW_BATCH': '1'})):
+            for k in ('PS_RSP', 'PS_NO_ROW_BATCH', 'PS_ROW2'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -511,17 +514,17 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
             st = s.chain_stats(0, nd)
             prof = s.prof_read()
             batched = prof['row_inv_x2'][1] + prof['row_inv_x4'][1] + prof['row_inv_x8'][1]
-            if tag == 'persistent' and start == 400:
+            if tag in ('persistent', 'two_role') and start == 400:
                 assert batched >= 3            # the chained groups went through one row launch each
-            if tag != 'persistent':
+            if tag not in ('persistent', 'two_role'):
                 assert batched == 0
             runs[tag] = ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st])
             s.close()
         assert any(f for f, _, _, _ in runs['oneshot'][1]) == (start != 400)
-        for tag in ('persistent', 'per_day'):
-            assert runs[tag][1] == runs['oneshot'][1]
+        for tag in ('persistent', 'per_day', 'two_role', 'two_role_per_day'):
+            assert runs[tag][1] == runs['oneshot'][1], tag
             for a, b in zip(runs[tag][0], runs['oneshot'][0]):
-                assert np.array_equal(a, b)
+                assert np.array_equal(a, b), tag
 
 
 def test_window_hint_changes_nothing(hip_lib, monkeypatch):
