@@ -55,9 +55,9 @@ PMC_NAME = {'row_inv': (('void k_row_inv',), None), 'col_inv_b': (('void k_col<1
             'col_inv_a': (('void k_col_fused<', 'void k_colfull_day<'), None)}
 for _n in (2, 4, 8):
     PMC_NAME['col_inv_a_x%d' % _n] = (('void k_col_fused_multi<false, %d,' % _n, 'void k_colfull<'), _n)
-    PMC_NAME['row_inv_x%d' % _n] = (('void k_row_inv_rsp<',), _n)
+    PMC_NAME['row_inv_x%d' % _n] = (('void k_row_inv_rsp<', 'void k_row_inv_rs2<'), _n)
 PMC_NAME['col_inv_a_xn'] = (('void k_colfull<', 'void k_colfull_dual<'), 0)   # 0: the cluster with the most dispatches
-PMC_NAME['row_inv_xn'] = (('void k_row_inv_rsp<',), 0)
+PMC_NAME['row_inv_xn'] = (('void k_row_inv_rsp<', 'void k_row_inv_rs2<'), 0)
 
 
 def launch_bytes(cls, N, fft_len, direct, kernel_rows_bytes=0.0, days=None):
@@ -142,7 +142,7 @@ def pmc_traffic(kernel_class):
             continue      # the forward / inverse / product instances of k_colfull are other classes
         if days is None and e.get('size_groups', 1) != 1:
             continue      # a kernel whose dispatches differ in size: not a single-day class
-        if days and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<')):
+        if days and e['kernel'].startswith(('void k_colfull<', 'void k_row_inv_rsp<', 'void k_row_inv_rs2<')):
             # the clusters of this kernel's dispatches by bytes written are its 2-, 4-, 8-day
             # launches in that order; a summary that does not hold all three cannot be attributed
             if e.get('size_groups') != 3 or e.get('size_rank') != (2, 4, 8).index(days):
