@@ -62,7 +62,7 @@ def real_wind_case(rad_dist, R=2048, nd=30, mode='fast', device=None, reps=3, pr
     s = pm.solver
     ks = pm.model.last['kshape']
     dt, stats = _chain_rate(pm, nd, reps)      # the rate: no per-launch events in the stream
-    kern = {}
+    kern, helpers = {}, {}
     if prof:                                   # the per-class table: the same chain again, with them
         s.prof_enable(True, every=1)
         _chain_rate(pm, nd, reps)
@@ -70,6 +70,13 @@ def real_wind_case(rad_dist, R=2048, nd=30, mode='fast', device=None, reps=3, pr
             if cnt:
                 kern[k] = {'launches_per_chain': round(cnt / reps, 1), 'avg_ms': round(ms / cnt, 4),
                            'ms_per_chain': round(ms / reps, 3)}
+        if s.mode == 'auto':                   # the helpers' launches, per owner (most of an auto chain)
+            for o in s.PROF_OWNERS[1:]:
+                t = {k: {'launches_per_chain': round(v['launches'] / reps, 1), 'avg_ms': round(v['ms'] / v['timed'], 4),
+                         'ms_per_chain': round(v['ms'] / reps, 3)} for k, v in s.prof_owner(o).items() if v['timed']}
+                if t:
+                    helpers[o] = {'fft_len': s.helper_fft_len(o), 'ms_per_chain': round(sum(v['ms_per_chain'] for v in t.values()), 3),
+                                  'kernels': t}
         s.prof_enable(False)
     flags = [bool(x.flag) for x in stats]
     last = stats[-1]
@@ -87,6 +94,10 @@ def real_wind_case(rad_dist, R=2048, nd=30, mode='fast', device=None, reps=3, pr
            'end_to_end_eval_s': round(t_eval, 4), 'first_eval_s': round(t_first, 3),
            'last_day_mass': round(last.sum + last.delta * last.nnz, 12), 'last_day_nnz': int(last.nnz),
            'kernels': kern}
+    if helpers:
+        rec['helper_kernels'] = helpers
+        rec['kernel_ms_accounted'] = round(sum(v['ms_per_chain'] for v in kern.values())
+                                           + sum(h['ms_per_chain'] for h in helpers.values()), 3)
     pm.close()
     return rec
 

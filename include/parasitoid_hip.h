@@ -235,6 +235,12 @@ int ps_prof_enable(ps_solver* s, int on);   /* 0 off, 1 every launch, n > 1 ever
 int ps_prof_read(ps_solver* s, int ncls, double* total_ms, int64_t* count); /* synchronises */
 int ps_prof_read_days(ps_solver* s, int ncls, int64_t* days); /* grid-days of the timed launches per class */
 int ps_prof_read_launches(ps_solver* s, int ncls, int64_t* launches); /* ALL launches per class since ps_prof_enable (timed or not) */
+/* the same four arrays for one owner of an auto-mode run: 0 the front itself, 1 wide, 2 fold child, 3 narrow
+ * (the numbering of ps_solver_auto_route).  ps_prof_enable on the front switches its helpers too, helpers
+ * attached later inherit it; a helper the run never needed reads as zeros. */
+int ps_prof_read_owner(ps_solver* s, int owner, int ncls, double* total_ms, int64_t* count, int64_t* launches,
+                       int64_t* days);
+int ps_solver_owner_fft(ps_solver* s, int owner); /* torus size of that owner, 0 while it does not exist */
 
 /* full P x P complex spectrum in/out (function-level CalcSol.fft2/fftconv2/ifft2 mirrors;
  * only valid in PS_MODE_EXACT) */

@@ -93,6 +93,8 @@ SIGNATURES = {
     'ps_prof_read': (C.c_int, [_VP, C.c_int, _F64P, _I64P]),
     'ps_prof_read_days': (C.c_int, [_VP, C.c_int, _I64P]),
     'ps_prof_read_launches': (C.c_int, [_VP, C.c_int, _I64P]),
+    'ps_prof_read_owner': (C.c_int, [_VP, C.c_int, C.c_int, _F64P, _I64P, _I64P, _I64P]),
+    'ps_solver_owner_fft': (C.c_int, [_VP, C.c_int]),
     'ps_solver_get_spectrum': (C.c_int, [_VP, _F64P]),
     'ps_solver_set_spectrum': (C.c_int, [_VP, _F64P]),
     'ps_model_create': (C.c_int, [C.POINTER(_VP), C.c_int]),

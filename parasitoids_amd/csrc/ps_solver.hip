@@ -1568,6 +1568,8 @@ static int auto_attach(ps_solver* s, ps_solver** slot, int mode, int max_shape, 
     c->borrowed = true;
     c->speculate = false;                 // predicated re-FFT: the window logic here does the host checks
     c->pad_floor = 0.5 * kCleanEps;
+    c->prof_on = s->prof_on;              // a profiled run times its helpers' launches too (ps_prof_read_owner)
+    c->prof_every = s->prof_every;
     *slot = c;
     *kernels_ok = false;
   }
@@ -2768,6 +2770,8 @@ extern "C" int ps_prof_enable(ps_solver* s, int on) {
   for (int i = 0; i < PS_PROF_NCLS; ++i) { s->prof_ms[i] = 0; s->prof_cnt[i] = 0; s->prof_seen[i] = 0; s->prof_days[i] = 0; }
   s->prof_on = on != 0;
   s->prof_every = on > 1 ? on : 1;   // on = n > 1: time every n-th launch of each class
+  for (ps_solver* c : {s->wide, s->child, s->narrow})   // the helpers of an auto-mode front follow it
+    if (c) PS_TRY(ps_prof_enable(c, on));
   return PS_OK;
 }
 
@@ -2800,6 +2804,20 @@ extern "C" int ps_prof_read_launches(ps_solver* s, int ncls, int64_t* launches) 
   return PS_OK;
 }
 
+extern "C" int ps_prof_read_owner(ps_solver* s, int owner, int ncls, double* total_ms, int64_t* count,
+                                  int64_t* launches, int64_t* days) {
+  if (!s || owner < 0 || owner > 3 || !total_ms || !count || !launches || !days)
+    return ps_fail(PS_ERR_BAD_ARG, "prof_read_owner: bad arguments");
+  ps_solver* c = owner == 1 ? s->wide : (owner == 2 ? s->child : (owner == 3 ? s->narrow : s));
+  if (!c) {   // a helper this run never needed
+    for (int i = 0; i < ncls; ++i) { total_ms[i] = 0.0; count[i] = 0; launches[i] = 0; days[i] = 0; }
+    return PS_OK;
+  }
+  PS_TRY(ps_prof_read(c, ncls, total_ms, count));
+  PS_TRY(ps_prof_read_launches(c, ncls, launches));
+  return ps_prof_read_days(c, ncls, days);
+}
+
 extern "C" int ps_solver_kernels_direct(ps_solver* s) { return s && s->kt_direct ? 1 : 0; }
 
 extern "C" int ps_solver_pipeline(ps_solver* s) { return s && s->tpipe ? 1 : 0; }
@@ -2818,6 +2836,12 @@ extern "C" int ps_solver_auto_info(ps_solver* s, int* first_fold_day, int* fold_
   if (first_fold_day) *first_fold_day = s->auto_exact ? s->auto_first : -1;
   if (fold_fft) *fold_fft = s->child ? s->child->Pf : 0;
   return PS_OK;
+}
+
+extern "C" int ps_solver_owner_fft(ps_solver* s, int owner) {
+  if (!s) return 0;
+  ps_solver* c = owner == 1 ? s->wide : (owner == 2 ? s->child : (owner == 3 ? s->narrow : (owner == 0 ? s : nullptr)));
+  return c ? c->Pf : 0;
 }
 
 int ps_solver_dom_len_internal(ps_solver* s) { return s->N; }

@@ -439,6 +439,24 @@ class HipSolve():
         L.check(self._lib.ps_prof_read_launches(self._h, n, L.p_i64(cnt)))
         return {k: int(cnt[i]) for i, k in enumerate(self.PROF_CLASSES)}
 
+    PROF_OWNERS = ('front', 'wide', 'fold', 'narrow')
+
+    def prof_owner(self, owner):
+        '''-> {class: dict(ms, timed, launches, days)} for one owner of an auto-mode run ('front', 'wide',
+        'fold', 'narrow' or 0..3, the numbering of auto_route); classes never launched are left out'''
+        o = self.PROF_OWNERS.index(owner) if isinstance(owner, str) else int(owner)
+        n = len(self.PROF_CLASSES)
+        ms = np.zeros(n)
+        cnt, lau, days = (np.zeros(n, dtype=np.int64) for _ in range(3))
+        L.check(self._lib.ps_prof_read_owner(self._h, o, n, L.p_f64(ms), L.p_i64(cnt), L.p_i64(lau), L.p_i64(days)))
+        return {k: dict(ms=float(ms[i]), timed=int(cnt[i]), launches=int(lau[i]), days=int(days[i]))
+                for i, k in enumerate(self.PROF_CLASSES) if lau[i] or cnt[i]}
+
+    def helper_fft_len(self, owner):
+        '''torus size of one owner of an auto-mode run (0 while that helper does not exist)'''
+        o = self.PROF_OWNERS.index(owner) if isinstance(owner, str) else int(owner)
+        return int(self._lib.ps_solver_owner_fft(self._h, o))
+
     def get_spectrum(self):
         P = self.fft_len
         out = np.empty((P, P), dtype=np.complex128)

@@ -478,6 +478,22 @@ def test_auto_mode_wide_helper_is_exact(hip_lib, golden, monkeypatch):
                 np.testing.assert_allclose(s.dense(0, d), trace['raw'][d], rtol=0, atol=1e-13)
                 assert bool(st[d].flag) == bool(trace['flags'][d]), (start, rep, d)
                 assert abs(s.chain_solution(d, st[d]).tocsr() - ref[d + 1].tocsr()).max() < 1e-12
+    # the per-owner kernel table of a profiled run: every helper that took days of the last run shows
+    # launches, and what the helpers add up to is most of the chain (bench.py's helper_kernels)
+    s.prof_enable(True)
+    s.set_state(state)
+    s.run_chain(renorm=True)
+    route = s.auto_route(0, nd)
+    assert np.array_equal(route, routes[-1])                     # profiling changes no route
+    for o, name in enumerate(s.PROF_OWNERS):
+        t = s.prof_owner(name)
+        assert t == s.prof_owner(o)
+        if o and (route == o).any():
+            assert s.helper_fft_len(name) > 0
+            assert sum(v['launches'] for v in t.values()) > 0 and sum(v['ms'] for v in t.values()) > 0, (name, t)
+        if o and not s.helper_fft_len(name):
+            assert t == {}
+    s.prof_enable(False)
     s.close()
     assert seen >= {0, 1, 2}, seen        # clean prefix, wide helper and fold child all took days
 
