@@ -45,7 +45,9 @@ struct ColFullArgs {
   int64_t dst_bstride;
   int ld, ncols, mode, store_prod;
   int nd;                // mode 0: consecutive days in this pass
-  int dst_t;             // dst is column-major [H][L] too (the inverse row pass reads it that way)
+  int dst_t;             // layout of dst (the inverse row pass reads it that way): 0 row-major [P][ld], 1 column-major
+                         // [H][L], 2 row pairs interleaved [P/2][ld][2] -- as the four coefficients below
+  int dst_jb, dst_cc, dst_rst;   // colfull_set_layout
   int64_t src_dstride, dst_dstride;   // per day
   RowLive live;          // rows of src that were never written (known zero); range advances 2 ints per day
   const unsigned long long* pred;
@@ -62,6 +64,28 @@ struct ColFullArgs {
   RowLive alt_live;
   FftProg prog;          // the length-L row plan (its two-level twiddle table)
 };
+
+// Where thread j of the last inverse stage puts its spatial rows j + q T3 of column c: `rst` elements apart per
+// T3 rows in every layout (T3 = 16 R2 is even, so a row keeps its parity and its pair moves by T3 / 2).
+//   0  row-major [P][ld]: 16-byte stores, every lane in another 128-byte line; the eight columns of a line are
+//      eight workgroups of one XCD and meet in its L2
+//   1  column-major [H][L] (PS_TINV): contiguous stores, but the row pass then gathers
+//   2  row pairs interleaved [P/2][ld][2]: element (r, c) at ((r >> 1) ld + c) 2 + (r & 1).  Lanes 2i and 2i + 1
+//      store 32 contiguous bytes -- half as many memory requests per store instruction, four columns to a line
+//      (30-day two-role launch at 5184: 4.36 -> 4.00 ms; eight rows to a block instead of two: 3.92, not worth
+//      what it does to the row pass) -- and the row pass, which transforms rows 2p and 2p + 1 as ONE complex row,
+//      finds both in one contiguous stream (fft_rs_kernels.h: pair_src)
+// One linear form for all three, its coefficients set by the host (colfull_set_layout): element offset of row j
+// of column c = j dst_rst + (j & 1) dst_jb + c dst_cc, T3 more rows = T3 dst_rst more elements -- a 32-bit lane
+// offset on top of uniform bases, one address register for all R3 stores, no layout test in the kernel (a
+// three-way select at this point of k_colfull_dual cost 23 spilled registers).
+inline void colfull_set_layout(ColFullArgs& a, int lay, int L) {
+  a.dst_t = lay;
+  a.dst_jb = lay == 2 ? 1 - a.ld : 0;
+  a.dst_cc = lay == 1 ? L : (lay == 2 ? 2 : 1);
+  a.dst_rst = lay == 1 ? 1 : a.ld;
+}
+#define PS_COLFULL_OFF(a, c, j) ((unsigned)((j) * (a).dst_rst + ((j) & 1) * (a).dst_jb + (c) * (a).dst_cc))
 
 // One block per day: total pad-row energy of the day's intermediate (fixed summation order) ->
 // quiet[day] = 1 when even the total passes the per-pair Parseval test of the inverse row pass
@@ -205,10 +229,11 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull_day(ColFullA
   if constexpr (CEX) rs_tail_c<S, R1, R2, R3, PS_INV>(x, exc, j, w2, w3);     // thread j < T3: spatial rows j + q T3
   else rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2, w3);
   if (j < S::T3) {
-    cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (a.dst_t ? (int64_t)c * L : (int64_t)c);
-    const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
+    const int64_t rst = a.dst_rst;
+    const unsigned off = PS_COLFULL_OFF(a, c, j);
+    cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
 #pragma unroll
-    for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = x[q];
+    for (int q = 0; q < R3; ++q) (d + (int64_t)(q * S::T3) * rst)[off] = x[q];
   }
 }
 
@@ -249,10 +274,11 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
     }
     rs_tail<S, R1, R2, R3, PS_INV>(x, ex, j, w2c, w3c);
     if (j < S::T3) {
-      cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (a.dst_t ? (int64_t)c * L : (int64_t)c);
-      const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
+      const int64_t rst = a.dst_rst;
+      const unsigned off = PS_COLFULL_OFF(a, c, j);
+      cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride;
 #pragma unroll
-      for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = x[q];
+      for (int q = 0; q < R3; ++q) (d + (int64_t)(q * S::T3) * rst)[off] = x[q];
     }
     if (a.pad_energy) {   // as k_colfull_dual: |x|^2 over the pad-only rows of this column and day
       double pe = 0.0;
@@ -391,11 +417,11 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_colfull(ColFullArgs 
         if (jv < S::T1) bfly<R1, PS_INV>(x);
         rs_tail<S, R1, R2, R3, PS_INV>(x, ex, jv, w2, w3);     // thread jv < T3: spatial rows jv + q T3
         if (jv < S::T3) {
-          cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)day * a.dst_dstride +
-                    (a.dst_t ? (int64_t)c * L : (int64_t)c);
-          const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
+          const int64_t rst = a.dst_rst;
+          const unsigned off = PS_COLFULL_OFF(a, c, jv);
+          cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)day * a.dst_dstride;
 #pragma unroll
-          for (int q = 0; q < R3; ++q) d[(int64_t)(jv + q * S::T3) * rst] = x[q];
+          for (int q = 0; q < R3; ++q) (d + (int64_t)(q * S::T3) * rst)[off] = x[q];
         }
         if (day + 1 < nd) __syncthreads();   // the exchange buffer is reused by the next day's transform
       }
@@ -656,11 +682,10 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_colfull_dual(Col
     if (act && j < S::T3) rs_stage<R3, PS_FWD>(x, w3, true);
     if (act && j < S::T3) {
       if (role == 0) {                                     // conj: spatial rows j + q T3 of day slot - 1
-        cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)(slot - 1) * a.dst_dstride +
-                  (a.dst_t ? (int64_t)c * L : (int64_t)c);
-        const int64_t rst = a.dst_t ? 1 : (int64_t)a.ld;
+        const int64_t rst = a.dst_rst;
+        cplx* d = a.dst + (int64_t)blockIdx.y * a.dst_bstride + (int64_t)(slot - 1) * a.dst_dstride + PS_COLFULL_OFF(a, c, j);
 #pragma unroll
-        for (int q = 0; q < R3; ++q) d[(int64_t)(j + q * S::T3) * rst] = cconj(x[q]);
+        for (int q = 0; q < R3; ++q) d[(int64_t)(q * S::T3) * rst] = cconj(x[q]);
       } else {                                             // X[j + q T3] of day slot's kernel column
 #pragma unroll
         for (int q = 0; q < R3; ++q) {

@@ -97,6 +97,8 @@ struct RowInvArgs {
   int64_t src_bstride;
   int H, ld, P, N;
   int tstride;   // != 0 (register-resident kernel only): src is column-major [H][tstride] (full-column pipeline)
+  int pair_src;  // != 0 (register-resident kernels, P even): rows 2p and 2p + 1 interleaved element by element,
+                 // [P/2][ld][2] (ColFullArgs::dst_t == 2, fft_colfull_kernels.h: colfull_dst)
   int rp;
   double scale;  // 1 / Pfft^2
   double* rec;   // [N][N] raw real solution

@@ -50,10 +50,12 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR * NP)) k_row_inv_rs(RowI
   const cplx* src = a.src + (int64_t)blockIdx.y * a.src_bstride;
   const int ra = 2 * pair, rb = ra + 1;
   const bool hasb = rb < a.P;
-  // element k of row r: row-major at r * ld + k, column-major at k * tstride + r
-  const int64_t kst = a.tstride ? (int64_t)a.tstride : 1;
+  // element k of row r: row-major at r * ld + k, column-major at k * tstride + r, row pairs interleaved
+  // (pair_src; P even) at ((r >> 1) ld + k) 2 + (r & 1) -- row 2p starts where it does in the row-major layout
+  const int64_t kst = a.tstride ? (int64_t)a.tstride : (a.pair_src ? 2 : 1);
   const cplx* pa = src + (a.tstride ? (int64_t)ra : (int64_t)ra * a.ld);
-  const cplx* pb = src + (a.tstride ? (int64_t)(hasb ? rb : ra) : (int64_t)(hasb ? rb : ra) * a.ld);
+  const cplx* pb = a.pair_src ? pa + 1
+                              : src + (a.tstride ? (int64_t)(hasb ? rb : ra) : (int64_t)(hasb ? rb : ra) * a.ld);
   const bool pad_only = ra >= a.N;
   const FftProg& P = a.prog;
   const cplx w2 = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j));
@@ -377,31 +379,34 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
   double* ex = reinterpret_cast<double*>(ps_lds_raw);
   double* red = ex + Y::XW;      // two sets of 5 * NW wave partials, then NW energy sums
   double* ered = red + 10 * NW;
-  cplx* stA = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);
-  cplx* stB = stA + Z::HS;
+  cplx* st = reinterpret_cast<cplx*>(ex + Y::XW + Y::RED);   // two staged rows, 32 elements of A, 32 of B, ... (prefetch)
   const int j0 = threadIdx.x, lane = j0 & 63, wave = j0 >> 6;
   const FftProg& P = a.prog;
   const cplx w2c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j0));
   const cplx w3c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j0 < S::T3 ? S::tw3(j0) : 0);
 
-  // rows of unit u -> staging; every wave copies the chunks c = wave, wave + NW, ... (row A, then B)
+  // rows of unit u -> staging; every wave copies the chunks c = wave, wave + NW, ...  A chunk is 32 elements of
+  // row A (lanes 0-31) and the same 32 of row B (lanes 32-63): st[64 c + l].  From a row-major source that is
+  // two runs of 512 bytes; from the pair-interleaved one (pair_src: A[k], B[k] side by side from where row ra
+  // starts) ONE run of 1 KB -- the copy takes the rows apart, and the first stage reads the same staging
+  // either way.  (Staging whole rows one after the other, as this kernel did first, makes a lane stride of
+  // 32 bytes out of the interleaved source: every line fetched twice, 0.27 ms more per 30-day launch at 5184.)
   auto prefetch = [&](int u) {
     const int b = u / npairs, pair = u - b * npairs;
     if (a.pad_quiet && 2 * pair >= a.N && a.pad_quiet[b]) return;   // never read: see the round below
     const cplx* src = a.src + (int64_t)b * a.src_bstride;
     const int ra = 2 * pair, rb = (ra + 1 < a.P) ? ra + 1 : ra;
     const cplx* pa = src + (int64_t)ra * a.ld;
-    const cplx* pb = src + (int64_t)rb * a.ld;
+    const int ksh = a.pair_src ? 1 : 0;
+    const int bofs = (lane >> 5) ? (a.pair_src ? 1 : (rb - ra) * a.ld) : 0;
 #pragma unroll
     for (int t = 0; t < (2 * NCH + NW - 1) / NW; ++t) {
       const int c = wave + t * NW;             // wave-uniform
       if (c < 2 * NCH) {
-        const bool isb = c >= NCH;
-        const int cc = isb ? c - NCH : c;
-        int k = cc * 64 + lane;
+        int k = c * 32 + (lane & 31);
         k = k < H ? k : H - 1;                 // the last chunk: stay inside the row
-        const cplx* g = (isb ? pb : pa) + k;
-        cplx* d = (isb ? stB : stA) + cc * 64; // + lane * 16 B by the instruction
+        const cplx* g = pa + ((k << ksh) + bofs);
+        cplx* d = st + c * 64;                 // + lane * 16 B by the instruction
         __builtin_amdgcn_global_load_lds(g, (ps_lds_ptr)d, 16, 0, 0);
       }
     }
@@ -472,8 +477,9 @@ __global__ void __launch_bounds__((Rs<R1, R2, R3>::NTHR)) k_row_inv_rsp(RowInvAr
         const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);   // j + q T1 <= L/2
         const int i = j + q * S::T1;
         const int k = direct ? i : L - i;
-        const cplx A = stA[k];
-        cplx B = stB[k];
+        const int slot = k + (k & ~31);          // element k of row A; row B's 32 behind
+        const cplx A = st[slot];
+        cplx B = st[slot + 32];
         if (!hasb) B = make_double2(0.0, 0.0);
         if (direct) energy += A.x * A.x + A.y * A.y + B.x * B.x + B.y * B.y;
         x[q] = direct ? make_double2(A.x - B.y, A.y + B.x) : make_double2(A.x + B.y, B.x - A.y);
@@ -616,8 +622,7 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_row_inv_rs2(RowI
   const int j0 = threadIdx.x - role * S::NTHR, lane = j0 & 63, wave = __builtin_amdgcn_readfirstlane(j0 >> 6);
   double* red = ex + Y::XW + role * Z::RED;                 // this role's 5 NW partials
   double* ered = red + 5 * NW;                              // ... and NW energy sums
-  cplx* stA = reinterpret_cast<cplx*>(ex + Y::XW + 2 * Z::RED);
-  cplx* stB = stA + Z::HS;
+  cplx* st = reinterpret_cast<cplx*>(ex + Y::XW + 2 * Z::RED);   // two staged rows in chunks of 32 + 32 (k_row_inv_rsp)
   const FftProg& P = a.prog;
   const cplx w2c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, S::tw2(j0));
   const cplx w3c = tw_lookup(P.tw_lo, P.tw_hi, P.tw_shift, j0 < S::T3 ? S::tw3(j0) : 0);
@@ -648,28 +653,30 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_row_inv_rs2(RowI
   bool loaded = false;        // the copy of unit cur's rows is on its way to (or in) the staging area
   bool done = false;          // x holds unit cur's transformed rows: the epilogue is due
 
-  // rows of unit u -> staging; every wave of the role copies the chunks c = wave, wave + NW, ... (row A, then B)
+  // rows of unit u -> staging; every wave of the role copies the chunks c = wave, wave + NW, ... (32 elements
+  // of row A and of row B each, see k_row_inv_rsp)
   auto prefetch = [&](int u) {
     const int b = u / npairs, pair = u - b * npairs;
     const cplx* src = a.src + (int64_t)b * a.src_bstride;
     const int ra = 2 * pair, rb = (ra + 1 < a.P) ? ra + 1 : ra;
     const cplx* pa = src + (int64_t)ra * a.ld;
-    const cplx* pb = src + (int64_t)rb * a.ld;
+    const int ksh = a.pair_src ? 1 : 0;
+    const int bo = a.pair_src ? 1 : (rb - ra) * a.ld;          // uniform: from an element of row A to row B's
     // (opaque lane: the per-lane element indices are loop-invariant, and at this kernel's register limit the
     // compiler kept them in scratch -- a scratch reload and a wait for ALL outstanding copies in front of
     // every copy instruction, i.e. one copy at a time)
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    const int bofs = (ln >> 5) ? bo : 0;
+    ln &= 31;
 #pragma unroll
     for (int t = 0; t < (2 * NCH + NW - 1) / NW; ++t) {
       const int c = wave + t * NW;             // wave-uniform
       if (c < 2 * NCH) {
-        const bool isb = c >= NCH;
-        const int cc = isb ? c - NCH : c;
-        int k = cc * 64 + ln;
+        int k = c * 32 + ln;
         k = k < H ? k : H - 1;                 // the last chunk: stay inside the row
-        const cplx* g = (isb ? pb : pa) + k;
-        cplx* d = (isb ? stB : stA) + cc * 64; // + lane * 16 B by the instruction
+        const cplx* g = pa + ((k << ksh) + bofs);
+        cplx* d = st + c * 64;                 // + lane * 16 B by the instruction
         __builtin_amdgcn_global_load_lds(g, (ps_lds_ptr)d, 16, 0, 0);
       }
     }
@@ -763,8 +770,9 @@ __global__ void __launch_bounds__((2 * Rs<R1, R2, R3>::NTHR)) k_row_inv_rs2(RowI
         const bool direct = (q < R1 / 2) || (q == R1 / 2 && j == 0);   // j + q T1 <= L/2
         const int i = j + q * S::T1;
         const int k = direct ? i : L - i;
-        const cplx A = stA[k];
-        cplx B = stB[k];
+        const int slot = k + (k & ~31);          // element k of row A; row B's 32 behind
+        const cplx A = st[slot];
+        cplx B = st[slot + 32];
         if (!hasb) B = make_double2(0.0, 0.0);
         if (direct) energy += A.x * A.x + A.y * A.y + B.x * B.x + B.y * B.y;
         x[q] = direct ? make_double2(A.x - B.y, A.y + B.x) : make_double2(A.x + B.y, B.x - A.y);

@@ -46,6 +46,7 @@
   X("PS_RSP", rsp, -1, INT, R)                                                                      \
   X("PS_ROW2", row2, -1, INT, R)                                                                    \
   X("PS_TPIPE", tpipe, -1, INT, R)                                                                  \
+  X("PS_NO_PAIR_ROWS", no_pair_rows, 0, FLAG, R)                                                    \
   X("PS_TPIPE_SPLIT", tpipe_split, 0, INT, R)                                                       \
   X("PS_NO_CONJ", no_conj, 0, FLAG, R)                                                              \
   X("PS_NO_DUAL", no_dual, 0, FLAG, R)                                                              \

@@ -468,6 +468,18 @@ static bool row_inv_persistent(const ps_solver* s) {
   return knob == 1 || (s->tpipe && s->Pf >= 1536);
 }
 
+// Layout of the intermediate between the inverse column pass and the inverse row pass of the full-column
+// pipeline (ColFullArgs::dst_t): 1 column-major (PS_TINV, an A/B leg), 2 row pairs interleaved -- the default:
+// the column pass's lanes 2i, 2i + 1 store 32 contiguous bytes instead of 16 in two lines, and the row pass
+// transforms rows 2p, 2p + 1 as one complex row anyway (fft_colfull_kernels.h: colfull_dst; the 30-day
+// two-role launch at 5184: 4.36 -> 4.00 ms) -- 0 row-major (PS_NO_PAIR_ROWS, fold mode: k_row_inv_fold pairs
+// other rows).  The same values in other places: every result is bit-identical.
+static int inter_layout(const ps_solver* s) {
+  if (!s->tpipe) return 0;
+  if (s->tinv) return 1;
+  return (s->mode != PS_MODE_FOLD && !s->cfg.no_pair_rows && s->Pf % 2 == 0) ? 2 : 0;
+}
+
 // `recs_multi` != nullptr: batch entry b writes recs_multi[b] (separately allocated day records;
 // needs row_inv_persistent(s) and batch <= 8)
 static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_slot, int batch,
@@ -491,6 +503,7 @@ static int launch_row_inv(ps_solver* s, const cplx* src, double* rec, int stat_s
   a.src = src; a.src_bstride = (int64_t)s->Pf * s->ld;
   a.H = s->H; a.ld = s->ld; a.P = s->Pf; a.N = s->N;
   a.tstride = (s->tpipe && s->tinv && !full_field) ? s->Pf : 0;   // full-column pipeline: column-major intermediate
+  a.pair_src = (!full_field && inter_layout(s) == 2) ? 1 : 0;
   a.prog = s->row_plan.prog;
   a.rp = row_pairs(a.prog);
   a.scale = 1.0 / ((double)s->Pf * (double)s->Pf);
@@ -571,7 +584,7 @@ static int launch_colfull(ps_solver* s, int mode, const cplx* src, cplx* state, 
   a.dst = dst; a.dst_bstride = spec;
   a.ld = s->ld; a.ncols = ncols >= 0 ? ncols : s->H; a.mode = mode; a.store_prod = store_prod;
   a.nd = nd; a.src_dstride = spec; a.dst_dstride = spec;
-  a.dst_t = s->tinv ? 1 : 0;
+  colfull_set_layout(a, s->tinv ? 1 : inter_layout(s), s->Pf);   // (after a.ld)
   a.live = live;
   a.pred = pred;
   a.prog = s->row_plan.prog;

@@ -479,8 +479,10 @@ def test_two_role_chained_pass_is_bit_identical(hip_lib, monkeypatch, R, K, fft)
         runs = {}
         for tag, env in (('dual', {}), ('single', {'PS_DUAL_MIN_DAYS': '0'}), ('read_all', {'PS_NO_PAD_QUIET': '1'}),
                          ('no_tail', {'PS_NO_TAIL_SPLIT': '1'}),
-                         ('row2', {'PS_ROW2': '1'})):          # the two-role row kernel (default only from 4096 points on)
-            for k in ('PS_DUAL_MIN_DAYS', 'PS_NO_PAD_QUIET', 'PS_NO_TAIL_SPLIT', 'PS_ROW2'):
+                         ('row2', {'PS_ROW2': '1'}),           # the two-role row kernel (default only from 4096 points on)
+                         # the intermediate row-major instead of row pairs interleaved (two-role pass, tail columns)
+                         ('row_major', {'PS_NO_PAIR_ROWS': '1'}), ('row_major_row2', {'PS_NO_PAIR_ROWS': '1', 'PS_ROW2': '1'})):
+            for k in ('PS_DUAL_MIN_DAYS', 'PS_NO_PAD_QUIET', 'PS_NO_TAIL_SPLIT', 'PS_ROW2', 'PS_NO_PAIR_ROWS'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -500,7 +502,7 @@ def test_two_role_chained_pass_is_bit_identical(hip_lib, monkeypatch, R, K, fft)
         flags = [f for f, *_ in runs['single'][1]]
         if want_flag is not None:
             assert any(flags) == want_flag, flags
-        for tag in ('dual', 'read_all', 'no_tail', 'row2'):
+        for tag in runs:
             assert runs[tag][1] == runs['single'][1], tag
             for a, b in zip(runs[tag][0], runs['single'][0]):
                 assert np.array_equal(a, b), tag

@@ -505,7 +505,10 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
     BIT-identical with PS_RSP=0 (one-shot kernel), PS_RSP=1 and PS_NO_ROW_BATCH=1 (one launch per
     day), and with k_row_inv_rs2 (PS_ROW2=1: two roles per workgroup in anti-phase, the default from 4096
     points on) -- un-flagged chained groups (2, 4, 8 days) and a flagged chain (single days, pad rows
-    that raise the flag, the Parseval skip of quiet pad-only pairs)."""
+    that raise the flag, the Parseval skip of quiet pad-only pairs).  Every column pass of the pipeline
+    (single day, chained, two-role chained, the tail columns) writes the intermediate in either layout --
+    row pairs interleaved or row-major (PS_NO_PAIR_ROWS=1) -- and every row kernel reads either: the same
+    values in other places, bit-identical results."""
     from parasitoids_amd import synthetic
     R, K, nd = 400, 401, 16
     N = 2 * R + 1
@@ -516,8 +519,13 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
         for tag, env in (('oneshot', {'PS_RSP': '0'}), ('persistent', {'PS_RSP': '1', 'PS_ROW2': '0'}),
                          ('per_day', {'PS_RSP': '1', 'PS_NO_ROW_BATCH': '1', 'PS_ROW2': '0'}),
                          ('two_role', {'PS_RSP': '1', 'PS_ROW2': '1'}),          # k_row_inv_rs2: two roles in anti-phase
-                         ('two_role_per_day', {'PS_RSP': '1', 'PS_ROW2': '1', 'PS_NO_ROW_BATCH': '1'})):
-            for k in ('PS_RSP', 'PS_NO_ROW_BATCH', 'PS_ROW2'):
+                         ('two_role_per_day', {'PS_RSP': '1', 'PS_ROW2': '1', 'PS_NO_ROW_BATCH': '1'}),
+                         # the intermediate between the column and the row pass row-major again instead of row pairs
+                         # interleaved (the default of the full-column pipeline): each of the three row kernels
+                         ('oneshot_row_major', {'PS_RSP': '0', 'PS_NO_PAIR_ROWS': '1'}),
+                         ('persistent_row_major', {'PS_RSP': '1', 'PS_ROW2': '0', 'PS_NO_PAIR_ROWS': '1'}),
+                         ('two_role_row_major', {'PS_RSP': '1', 'PS_ROW2': '1', 'PS_NO_PAIR_ROWS': '1'})):
+            for k in ('PS_RSP', 'PS_NO_ROW_BATCH', 'PS_ROW2', 'PS_NO_PAIR_ROWS'):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -530,14 +538,15 @@ def test_persistent_row_kernel_is_bit_identical(hip_lib, monkeypatch):
             st = s.chain_stats(0, nd)
             prof = s.prof_read()
             batched = prof['row_inv_x2'][1] + prof['row_inv_x4'][1] + prof['row_inv_x8'][1]
-            if tag in ('persistent', 'two_role') and start == 400:
+            if tag in ('persistent', 'two_role', 'persistent_row_major', 'two_role_row_major') and start == 400:
                 assert batched >= 3            # the chained groups went through one row launch each
-            if tag not in ('persistent', 'two_role'):
+            if 'oneshot' in tag or 'per_day' in tag:
                 assert batched == 0
+            assert s.get_option('PS_NO_PAIR_ROWS') == float('row_major' in tag)
             runs[tag] = ([s.dense(0, d) for d in range(nd)], [(x.flag, x.nnz, x.sum, x.delta) for x in st])
             s.close()
         assert any(f for f, _, _, _ in runs['oneshot'][1]) == (start != 400)
-        for tag in ('persistent', 'per_day', 'two_role', 'two_role_per_day'):
+        for tag in runs:
             assert runs[tag][1] == runs['oneshot'][1], tag
             for a, b in zip(runs[tag][0], runs['oneshot'][0]):
                 assert np.array_equal(a, b), tag
