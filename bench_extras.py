@@ -392,6 +392,9 @@ def release_case(R, mode, rad_dist=10000.0, nd=30, reps=3):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             t0 = time.perf_counter()
+            Run.run_model(p, verbose=False)          # first call of the process: device allocations, first touch
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
             modelsol, days, ndays, tm = Run.run_model(p, verbose=False)
             t_all = time.perf_counter() - t0
             route = CalcSol.last_release_route
@@ -404,7 +407,7 @@ def release_case(R, mode, rad_dist=10000.0, nd=30, reps=3):
     ms = np.max([q.shape for q in pmf_list], axis=0)
     r_spread = [Run.recentre(pmf_list[d], R).tocsr() for d in range(p.r_dur)]
     rec = {'rad_res': R, 'grid': '%d^2' % N, 'rad_dist': rad_dist, 'r_dur': p.r_dur, 'days': ndays, 'mode_asked': mode,
-           'route': route, 'end_to_end_s': round(t_all, 3), 'prob_mass_s': round(tm['prob_mass_s'], 3),
+           'route': route, 'first_call_s': round(t_first, 3), 'end_to_end_s': round(t_all, 3), 'prob_mass_s': round(tm['prob_mass_s'], 3),
            'get_populations_s': round(tm['solver_s'], 3), 'last_day_total': round(float(modelsol[-1].sum()), 3)}
     s = hip_lib.HipSolve(r_spread[-1], ms, mode='fast' if mode == 'fast' else mode, chain_only=True)
     try:
