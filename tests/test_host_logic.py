@@ -308,3 +308,15 @@ def test_two_role_pass_compiles_without_scratch(tmp_path):
         # the two radix-20 sizes the library enables spill 1-6 registers (measured: still well ahead of the
         # single-role pass -- 30-day launch at 5120 with 6 spilled: 3.45 against 4.42 ms); everything else none
         assert sp <= (6 if 'Li20E' in n else 0) and v <= 168, (n, v, sp)
+
+
+def test_every_option_is_documented():
+    """The knob table of the library (csrc/ps_config.h) and the table a caller reads list the
+    same keys: an option added without a word on what it does fails here."""
+    import re
+    keys = re.findall(r'X\("(PS_[A-Z0-9_]+)"', open(os.path.join(ROOT, 'parasitoids_amd', 'csrc', 'ps_config.h')).read())
+    assert len(keys) == len(set(keys)) >= 50
+    design = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    section = design[design.index('### 6.2 Tuning'):design.index('## 7. Multi-GPU')]
+    missing = [k for k in keys if k not in section]
+    assert not missing, missing
