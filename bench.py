@@ -637,6 +637,7 @@ def main():
             import bench_extras
             for key, fn in (('real_wind', bench_extras.real_wind_record),
                             ('release', lambda device=None: bench_extras.release_record()),
+                            ('prefix_split', lambda device=None: bench_extras.prefix_split_record(device=device)),
                             ('bayes', bench_extras.bayes_record)):
                 try:
                     out[key] = fn(device=local)

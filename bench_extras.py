@@ -442,6 +442,64 @@ def release_record():
     return out
 
 
+def prefix_split_record(G=8, R=2048, K=2049, nd=30, device=None):
+    """SURVEY 8e row 2 on the headline stack, the G "ranks" as G solvers of this one GPU
+    (parallel.chain_prefix_split_local): what every rank computes -- its block's kernel transforms and running
+    products, then its days' records from state x earlier totals x own products -- timed rank by rank, next to
+    the sequential chain of one solver.  The exchange itself (an all-gather of one spectrum per rank) cannot be
+    measured on one card: its volume is reported."""
+    from parasitoids_amd import hip_lib, parallel, synthetic
+    state, kernels, _ = synthetic.make_stack(R=R, K=K, ndays=nd, seed=20240613)
+    seq = hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True, device=device)
+    seq.set_kernels(kernels)
+    for _ in range(2):
+        seq.set_state(state)
+        seq.run_chain(renorm=True)
+    seq.sync()
+    t0 = time.perf_counter()
+    seq.set_state(state)
+    seq.run_chain(renorm=True)
+    seq.sync()
+    t_seq = time.perf_counter() - t0
+    blocks = parallel.split_days(nd, G)
+    solvers = [hip_lib.HipSolve(state, [K, K], mode='fast', chain_only=True, device=device) for _ in range(G)]
+    for s in solvers:
+        s.set_kernels(kernels)
+    tp, tf, totals = [0.0] * G, [0.0] * G, [None] * G
+    for rep in range(2):                      # the second round is the one reported (buffers exist)
+        for g, (s, (f, c)) in enumerate(zip(solvers, blocks)):
+            s.set_state(state)
+            s.sync()
+            t0 = time.perf_counter()
+            totals[g], nbytes = s.block_prefix(f, c)
+            tp[g] = time.perf_counter() - t0
+        flagged = False
+        for g in reversed(range(G)):          # see chain_prefix_split_local
+            f, c = blocks[g]
+            s = solvers[g]
+            t0 = time.perf_counter()
+            flagged = s.block_finish(f, c, totals[:g]) or flagged
+            s.sync()
+            tf[g] = time.perf_counter() - t0
+    worst = 0.0
+    for s, (f, c) in zip(solvers, blocks):
+        for d in (f, f + c - 1):
+            worst = max(worst, float(np.abs(s.dense(0, d) - seq.dense(0, d)).max()))
+    rec = {'workload': 'headline stack (N = %d, %d days, FFT %d) as %d blocks of days on ONE GPU, one solver per block'
+                       % (2 * R + 1, nd, seq.fft_len, G),
+           'blocks': blocks, 'flagged': bool(flagged),
+           'per_rank_prefix_ms': [round(t * 1e3, 3) for t in tp], 'per_rank_finish_ms': [round(t * 1e3, 3) for t in tf],
+           'slowest_rank_ms': round(max(a + b for a, b in zip(tp, tf)) * 1e3, 3),
+           'sequential_chain_ms': round(t_seq * 1e3, 3),
+           'exchange_bytes_into_each_rank': int((G - 1) * nbytes), 'block_total_bytes': int(nbytes),
+           'max_abs_vs_sequential': worst,
+           'note': 'per-rank compute only; the all-gather of the block totals (RCCL over xGMI) is not in these times'}
+    for s in solvers:
+        s.close()
+    seq.close()
+    return rec
+
+
 # --------------------------------------------------------------------------- N > 1: configs 4 and 5
 def _ensemble_runner(device, rad_res, ndays):
     """member -> result dict on this rank's GPU (BASELINE config 5: probability model, Carnarvon wind)"""
@@ -603,5 +661,7 @@ if __name__ == '__main__':
         print(json.dumps(prob_mass_roofline()))
     elif which == 'release':
         print(json.dumps(release_record()))
+    elif which == 'prefix_split':
+        print(json.dumps(prefix_split_record()))
     else:
         print(json.dumps(bayes_record()))

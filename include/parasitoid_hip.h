@@ -183,6 +183,28 @@ int ps_chain_stats(ps_solver* s, int first, int count, ps_day_stats* out); /* sy
 int ps_chain_run_release(ps_solver* s, int first, int count, double negval, int nfilt, int nuse,
                          const double* weights, int* certified);
 
+/* One simulation split over G GPUs by days -- SURVEY.md 8e, the flag-free special case (the reference has no
+ * counterpart: CalcSol.py:140-201 is one sequential loop; while no day raises its boundary flag that loop is the
+ * product A_d = A_0 K_1 ... K_d of spectra, and products re-associate).  Every rank holds the same state and
+ * the kernels of (at least) its own days.
+ *   ps_chain_block_prefix: the running products L_i = K_first ... K_{first+i} of days [first, first+count)
+ *     (2-D spectra in the solver's own layout, kept in the solver); *total_dev = device pointer of the block
+ *     total L_{count-1}, *total_bytes its size -- valid until the next block call on s.  The ranks exchange
+ *     these (one all-gather; parasitoids_amd/parallel.py:chain_prefix_split).
+ *   ps_chain_block_finish: chain records and statistics of the same days from A_0 T_0 ... T_{nprev-1} L_i
+ *     (prev_totals: device pointers of the nprev EARLIER blocks' totals, in block order, on this device; same
+ *     layout, i.e. solvers of the same dom_len / max_shape); negval / stat_scale / renorm as ps_chain_run;
+ *     *flagged = 1 when one of these days raised the flag -- the split does not apply then, rerun with
+ *     ps_chain_run.  The state afterwards is the spectrum after the block's last day.
+ * Same transforms and epilogue as ps_chain_run, the spectral products in another order: a field differs from
+ * the sequential chain's by rounding only (tests/test_prefix_split_gpu.py: <= 1e-15 of the day's maximum over
+ * 14 days).  PS_MODE_FAST on a register-resident FFT size (PS_ERR_UNSUPPORTED otherwise). */
+int ps_chain_block_prefix(ps_solver* s, int first, int count, const void** total_dev, int64_t* total_bytes);
+int ps_chain_block_finish(ps_solver* s, int first, int count, int nprev, const void* const* prev_totals,
+                          double negval, double stat_scale, int renorm, int* flagged);
+/* device-to-device copy between a buffer of this library and a caller's (e.g. a tensor of the collective) */
+int ps_device_copy(void* dst, const void* src, int64_t bytes);
+
 /* ---- records (device-resident N x N fields) ----
  * kind 0: chain/get_cursol records, 1: back_solve records, 2: state (first day),
  * 3: scratch result of ps_weighted_sum. */

@@ -93,6 +93,10 @@ SIGNATURES = {
     'ps_prof_read': (C.c_int, [_VP, C.c_int, _F64P, _I64P]),
     'ps_prof_read_days': (C.c_int, [_VP, C.c_int, _I64P]),
     'ps_prof_read_launches': (C.c_int, [_VP, C.c_int, _I64P]),
+    'ps_chain_block_prefix': (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'ps_chain_block_finish': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_double,
+                                        C.c_int, C.POINTER(C.c_int)]),
+    'ps_device_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'ps_prof_read_owner': (C.c_int, [_VP, C.c_int, C.c_int, _F64P, _I64P, _I64P, _I64P]),
     'ps_solver_owner_fft': (C.c_int, [_VP, C.c_int]),
     'ps_solver_get_spectrum': (C.c_int, [_VP, _F64P]),

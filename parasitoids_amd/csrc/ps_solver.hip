@@ -288,6 +288,10 @@ struct ps_solver {
   // spectrum is FFT_columns(Trow), not Ahat -- the next day pass transforms the column itself
   // (k_colfull_day, alt_src), anything else goes through resolve_refft first
   DevBuf<cplx> Trow;
+  // ps_chain_block_prefix / _finish (one simulation split over GPUs by days): the running products
+  // K_first ... K_{first+i} of this solver's block of days, 2-D spectra in the pipeline's layout
+  DevBuf<cplx> blk;
+  int blk_first = -1, blk_count = 0;
   DevBuf<unsigned long long> one_flag;   // a pad maximum that always counts as "fired" (PS_MODE_FOLD day passes)
   const unsigned long long* refft_pending = nullptr;
   int ncu = 0;                 // compute units of the device
@@ -1174,7 +1178,7 @@ extern "C" int ps_solver_destroy(ps_solver* s) {
   s->row_plan.release(); s->col_plan1.release(); s->col_plan2.release();
   s->tp_lo.release(); s->tp_hi.release();
   s->Ahat.release(); s->Chat.release(); s->T1.release(); s->T2.release(); s->Bhat.release(); s->Fhat.release();
-  s->Trow.release(); s->one_flag.release(); s->tail_hat.release(); s->pad_energy.release(); s->pad_quiet.release();
+  s->Trow.release(); s->blk.release(); s->one_flag.release(); s->tail_hat.release(); s->pad_energy.release(); s->pad_quiet.release();
   s->srange.release();
   s->krow.release(); s->kcol.release(); s->kval.release(); s->kdense.release(); s->krange.release();
   for (auto& v : s->recs)
@@ -2518,6 +2522,111 @@ extern "C" int ps_chain_run_release(ps_solver* s, int first, int count, double n
     if (certified) *certified = ok;
     s->auto_first = -1;
   }
+  return PS_OK;
+}
+
+// ------------------------------------------------------------------ one simulation over G GPUs
+// While no day raises the boundary flag the chain is a product of spectra, A_d = A_0 K_1 ... K_d, and products
+// re-associate: the rank that owns days [first, first + count) forms L_i = K_first ... K_{first+i} on its own
+// (ps_chain_block_prefix), the ranks exchange their block totals L_{count-1} (ONE all-gather of a spectrum per
+// rank, parallel.chain_prefix_split), and every rank finishes its own days as A_0 (T_0 ... T_{g-1}) L_i
+// (ps_chain_block_finish).  Same transforms as the chain (kernel row pass, full column transform, inverse
+// column pass, inverse row pass with the usual epilogue); the PRODUCTS are taken in another order, so a day's
+// field differs from the sequential chain's in the last bits (<= a few 1e-16 of its maximum per day of the run;
+// tests/test_prefix_split_gpu.py), and a flag anywhere voids the split: *flagged tells, the caller reruns with
+// ps_chain_run.  Full-column pipeline only (fast mode on a register-resident size).
+extern "C" int ps_chain_block_prefix(ps_solver* s, int first, int count, const void** total_dev, int64_t* total_bytes) {
+  if (!s || first < 0 || count < 1 || !total_dev) return ps_fail(PS_ERR_BAD_ARG, "block_prefix: bad arguments");
+  if (s->mode != PS_MODE_FAST || !s->tpipe_ok)
+    return ps_fail(PS_ERR_UNSUPPORTED, "block_prefix: fast mode on a register-resident FFT size only (this solver: mode %d, size %d)", s->mode, s->Pf);
+  if (!s->have_state) return ps_fail(PS_ERR_STATE, "block_prefix before set_state");
+  if (!s->kernels_on_device || first + count > s->nk)
+    return ps_fail(PS_ERR_STATE, "block_prefix: days [%d,%d) not uploaded (nk=%d)", first, first + count, s->nk);
+  PS_HIP(hipSetDevice(s->device));
+  PS_TRY(resolve_refft(s));
+  if (!s->spec_valid) set_pipeline(s, true);
+  if (!s->tpipe) return ps_fail(PS_ERR_UNSUPPORTED, "block_prefix: the state's spectrum is held for the tiled pipeline; set the state again");
+  PS_TRY(ensure_spectrum(s));
+  const size_t spec = (size_t)s->Pf * s->ld;
+  const int64_t n = (int64_t)s->H * s->Pf;        // the column-major half spectrum [H][Pf]
+  PS_TRY(transform_kernels(s, first, count, 0, count, 0));
+  s->bhat_first = -1;                              // row-pass outputs only: nothing a later chain run could reuse as is
+  s->bhat_count = 0;
+  PS_TRY(s->blk.ensure(spec * count));
+  RowLive live = s->kt_live;
+  live.range = s->krange.p + 2 * first;
+  PS_TRY(launch_colfull(s, 1, s->Bhat.p, s->blk.p, 0, nullptr, count, live, nullptr));
+  for (int i = 1; i < count; ++i) {
+    hipLaunchKernelGGL(k_cmul_inplace, dim3(2048), dim3(256), 0, s->stream, s->blk.p + (size_t)i * spec,
+                       s->blk.p + (size_t)(i - 1) * spec, n);
+    PS_HIP(hipGetLastError());
+  }
+  s->blk_first = first;
+  s->blk_count = count;
+  *total_dev = s->blk.p + (size_t)(count - 1) * spec;
+  if (total_bytes) *total_bytes = (int64_t)(spec * sizeof(cplx));
+  PS_HIP(hipStreamSynchronize(s->stream));        // the caller hands the block total to a collective on another stream
+  return PS_OK;
+}
+
+extern "C" int ps_chain_block_finish(ps_solver* s, int first, int count, int nprev, const void* const* prev_totals,
+                                     double negval, double stat_scale, int renorm, int* flagged) {
+  if (!s || nprev < 0 || (nprev > 0 && !prev_totals)) return ps_fail(PS_ERR_BAD_ARG, "block_finish: bad arguments");
+  if (s->blk_first != first || s->blk_count != count || count < 1)
+    return ps_fail(PS_ERR_STATE, "block_finish: days [%d,%d) were not prepared by block_prefix", first, first + count);
+  PS_HIP(hipSetDevice(s->device));
+  const size_t spec = (size_t)s->Pf * s->ld;
+  const int64_t n = (int64_t)s->H * s->Pf;
+  PS_TRY(ensure_stats(s, std::max(4, s->nk)));
+  for (int d = first; d < first + count; ++d) PS_TRY(ensure_record(s, PS_REC_CHAIN, d));
+  PS_HIP(hipMemsetAsync(s->padmax.p + first, 0, (size_t)count * sizeof(unsigned long long), s->stream));
+  // what came before this block: A_0 T_0 ... T_{g-1}, the earlier blocks in their order
+  PS_TRY(s->Chat.ensure(spec));
+  PS_HIP(hipMemcpyAsync(s->Chat.p, s->Ahat.p, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
+  for (int j = 0; j < nprev; ++j) {
+    if (!prev_totals[j]) return ps_fail(PS_ERR_BAD_ARG, "block_finish: block total %d is null", j);
+    hipLaunchKernelGGL(k_cmul_inplace, dim3(2048), dim3(256), 0, s->stream, s->Chat.p, (const cplx*)prev_totals[j], n);
+    PS_HIP(hipGetLastError());
+  }
+  for (int i = 0; i < count; ++i) {
+    hipLaunchKernelGGL(k_cmul_inplace, dim3(2048), dim3(256), 0, s->stream, s->blk.p + (size_t)i * spec, s->Chat.p, n);
+    PS_HIP(hipGetLastError());
+  }
+  s->blk_first = -1;                               // the products are spent
+  s->blk_count = 0;
+  PS_TRY(s->T1.ensure(spec * count));
+  PS_TRY(launch_colfull(s, 2, nullptr, s->blk.p, 0, s->T1.p, count, RowLive{0, {0, 0, 0, 0}, nullptr}, nullptr));
+  if (row_inv_persistent(s) && !s->tinv && count <= PS_MAX_GROUP_DAYS && !s->cfg.no_row_batch) {
+    std::vector<double*> recs(count);
+    for (int i = 0; i < count; ++i) recs[i] = s->recs[PS_REC_CHAIN][first + i];
+    PS_TRY(launch_row_inv(s, s->T1.p, nullptr, first, count, negval, stat_scale, false, recs.data(), nullptr));
+  } else {
+    for (int i = 0; i < count; ++i)
+      PS_TRY(launch_row_inv(s, s->T1.p + (size_t)i * spec, s->recs[PS_REC_CHAIN][first + i], first + i, 1, negval, stat_scale));
+  }
+  s->last_renorm = renorm;
+  PS_TRY(finalize_days(s, first, count, renorm));
+  // the state after the block's last day, as a chain run would leave it
+  PS_HIP(hipMemcpyAsync(s->Ahat.p, s->blk.p + (size_t)(count - 1) * spec, spec * sizeof(cplx), hipMemcpyDeviceToDevice, s->stream));
+  s->noflag_hint = 0;
+  s->hist_count = 0;
+  std::vector<unsigned long long> h((size_t)count);
+  PS_HIP(hipMemcpyAsync(h.data(), s->padmax.p + first, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+  PS_HIP(hipStreamSynchronize(s->stream));
+  int any = 0;
+  for (unsigned long long v : h) {
+    double m;
+    __builtin_memcpy(&m, &v, sizeof(double));
+    if (!(m <= 1e-8)) any = 1;                     // NaN counts as flagged
+  }
+  if (flagged) *flagged = any;
+  return PS_OK;
+}
+
+// device-to-device copy between this library's buffers and a caller's (a tensor of the collective)
+extern "C" int ps_device_copy(void* dst, const void* src, int64_t bytes) {
+  if (!dst || !src || bytes < 0) return ps_fail(PS_ERR_BAD_ARG, "device_copy: bad arguments");
+  PS_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice));
   return PS_OK;
 }
 

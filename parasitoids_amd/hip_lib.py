@@ -320,6 +320,29 @@ class HipSolve():
                                                L.p_f64(w), C.byref(ok)))
         return bool(ok.value)
 
+    def block_prefix(self, first, count):
+        '''One simulation over several GPUs (ps_chain_block_prefix): the running products of the day
+        kernels [first, first+count) stay in the solver; -> (device pointer, bytes) of the block total, valid
+        until the next block call (parallel.chain_prefix_split exchanges these).'''
+        ptr, nbytes = C.c_void_p(), C.c_int64(0)
+        L.check(self._lib.ps_chain_block_prefix(self._h, int(first), int(count), C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def block_finish(self, first, count, prev_totals=(), negval=1e-8, scale=1.0, renorm=True):
+        '''... and the chain records / statistics of those days from state x (earlier blocks' totals, device
+        pointers in block order) x own products (ps_chain_block_finish).  -> True when one of the days raised
+        the boundary flag: the split does not apply, rerun with run_chain.'''
+        n = len(prev_totals)
+        arr = (C.c_void_p * max(n, 1))(*[int(p) for p in prev_totals])
+        flag = C.c_int(0)
+        L.check(self._lib.ps_chain_block_finish(self._h, int(first), int(count), n, arr, negval, scale,
+                                                int(bool(renorm)), C.byref(flag)))
+        return bool(flag.value)
+
+    def device_copy(self, dst_ptr, src_ptr, nbytes):
+        '''device-to-device copy between raw pointers (a block total into a tensor of the collective)'''
+        L.check(self._lib.ps_device_copy(C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)), int(nbytes)))
+
     def run_chain(self, first=0, count=None, negval=1e-8, scale=1.0, renorm=True):
         '''Enqueue days [first, first+count) of the uploaded kernels (no host sync).'''
         count = self._nk - first if count is None else count

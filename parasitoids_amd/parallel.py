@@ -7,7 +7,9 @@ solver over the ranks of a node.
  * whole simulations (MCMC chains, ensemble members) are independent -- round-robin
    over ranks, gather the results on rank 0.
  * the day chain of ONE simulation is a sequential recurrence (the boundary flag decides
-   each day whether the state is truncated) and stays on one GPU: replicas only.
+   each day whether the state is truncated) and stays on one GPU: replicas only -- except while
+   no day raises the flag: then it is a product of spectra and splits over the ranks by days
+   with ONE all-gather of a spectrum per rank (`chain_prefix_split`).
 
 Collectives: `torch.distributed` broadcast / all_gather / gather only ("nccl" = RCCL over
 xGMI on the GPU box, "gloo" on CPU for the tests).  Messages are small (<~1 MB per day
@@ -302,3 +304,84 @@ def run_members(members, fn, dst=0):
         return None
     flat = dict(kv for part in parts for kv in part)
     return [flat[i] for i in range(len(members))]
+
+
+# ------------------------------------------------------------------ one simulation over G GPUs
+def split_days(nd, world):
+    """contiguous blocks of days, one per rank, sizes differing by at most one -> [(first, count)]"""
+    base, rem = divmod(int(nd), int(world))
+    out, first = [], 0
+    for r in range(world):
+        c = base + (1 if r < rem else 0)
+        out.append((first, c))
+        first += c
+    return out
+
+
+class DeviceBlockOps:
+    """The two halves of a rank's work in `chain_prefix_split` on a `HipSolve` (fast mode, state set, all day
+    kernels uploaded): the block's running products stay in the solver, its total travels as a float64 tensor
+    on this rank's device (torch imported before the library touched the GPU)."""
+
+    def __init__(self, solver, negval=1e-8, scale=1.0, renorm=True):
+        self.s, self.negval, self.scale, self.renorm = solver, negval, scale, renorm
+
+    def prefix(self, first, count):
+        import torch
+        ptr, nbytes = self.s.block_prefix(first, count)
+        t = torch.empty(nbytes // 8, dtype=torch.float64, device=torch.device('cuda', torch.cuda.current_device()))
+        torch.cuda.synchronize()
+        self.s.device_copy(t.data_ptr(), ptr, nbytes)
+        return t
+
+    def finish(self, first, count, prev):
+        return self.s.block_finish(first, count, [t.data_ptr() for t in prev], self.negval, self.scale, self.renorm)
+
+
+def chain_prefix_split(ops, nd):
+    """ONE simulation's flag-free day chain over the ranks (no counterpart in the reference,
+    whose CalcSol.py:140-201 loop is sequential): rank g owns the g-th contiguous block of the nd days.
+        total = ops.prefix(first, count)        running products of the block's kernel spectra, their last one
+        all_gather(total)                       the only exchange: one spectrum per rank, GPU to GPU under RCCL
+        ops.finish(first, count, totals[:g])    the block's day records from state x earlier totals x own products
+    -> (first, count, flagged): this rank's block, and whether ANY rank saw the boundary flag -- then the split
+    does not apply (a flagged day is truncated and re-transformed before the next one) and every rank knows to
+    take the sequential route (`run_chain` on one of them).  nd >= world (every rank owns a day)."""
+    import torch
+    dist = _dist()
+    rank, world = rank_world()
+    if nd < world:
+        raise ValueError('chain_prefix_split: %d days for %d ranks' % (nd, world))
+    first, count = split_days(nd, world)[rank]
+    total = ops.prefix(first, count)
+    if world > 1:
+        via_host = total.is_cuda and dist.get_backend() != 'nccl'      # gloo rehearsal: no device collectives
+        w = total.cpu() if via_host else total
+        outs = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(outs, w)
+        prev = [o.to(total.device) if via_host else o for o in outs[:rank]]
+    else:
+        prev = []
+    flagged = bool(ops.finish(first, count, prev))
+    if world > 1:
+        f = torch.tensor([int(flagged)], dtype=torch.int32)
+        if dist.get_backend() == 'nccl':
+            f = f.to(total.device)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        flagged = bool(int(f.item()))
+    return first, count, flagged
+
+
+def chain_prefix_split_local(solvers, nd, negval=1e-8, scale=1.0, renorm=True):
+    """The same split with the "ranks" in ONE process: len(solvers) solvers on one GPU (same state, same
+    kernels), the block totals handed over as device pointers instead of through a collective -- what the tests
+    and `bench_extras.prefix_split_record` run on the one-GPU box.  -> ([(first, count)], flagged)"""
+    blocks = split_days(nd, len(solvers))
+    totals = [s.block_prefix(f, c)[0] for s, (f, c) in zip(solvers, blocks)]
+    flagged = False
+    # last block first: block_finish turns a solver's products into its days' spectra IN PLACE, and the pointers
+    # in `totals` are those very buffers (the collective of chain_prefix_split hands out copies instead)
+    for g in reversed(range(len(solvers))):
+        f, c = blocks[g]
+        flagged = solvers[g].block_finish(f, c, totals[:g], negval, scale, renorm) or flagged
+    return blocks, flagged

@@ -104,3 +104,87 @@ def test_shard_and_owner():
     back = parallel._unpack(*parallel._pack(m))
     for a, b in zip(m, back):
         assert (a != b).nnz == 0
+
+
+class _NumpyBlockOps:
+    """CPU stand-in for parallel.DeviceBlockOps: the same two halves with numpy FFTs on a small torus (the
+    exchange and the bookkeeping of chain_prefix_split are what is under test)."""
+
+    def __init__(self, state, kernels):
+        import torch
+        self.torch = torch
+        self.A0 = np.fft.fft2(state)
+        self.K = [np.fft.fft2(k) for k in kernels]
+        self.fields = {}
+        self.prev_seen = None
+
+    def prefix(self, first, count):
+        run, self.L = None, []
+        for d in range(first, first + count):
+            run = self.K[d] if run is None else run * self.K[d]
+            self.L.append(run)
+        return self.torch.from_numpy(np.ascontiguousarray(self.L[-1]).view(np.float64).ravel().copy())
+
+    def finish(self, first, count, prev):
+        P = self.A0
+        self.prev_seen = len(prev)
+        for t in prev:
+            P = P * t.numpy().view(np.complex128).reshape(self.A0.shape)
+        for i in range(count):
+            self.fields[first + i] = np.fft.ifft2(P * self.L[i]).real
+        return False
+
+
+def _split_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      LOCAL_RANK=str(rank))
+    from parasitoids_amd import parallel
+    import torch.distributed as dist
+    parallel.init('gloo')
+    rng = np.random.default_rng(5)
+    P, nd = 24, 7
+    state = np.zeros((P, P)); state[3, 4] = 1.0
+    kernels = []
+    for _ in range(nd):
+        k = np.zeros((P, P)); k[:3, :3] = rng.random((3, 3)); kernels.append(k / k.sum())
+    ops = _NumpyBlockOps(state, kernels)
+    first, count, flagged = parallel.chain_prefix_split(ops, nd)
+    q.put((rank, dict(first=first, count=count, flagged=flagged, prev=ops.prev_seen, fields=ops.fields)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prefix_split_exchange_two_ranks():
+    """SURVEY 8e row 2 under gloo, world size 2: rank 0 owns days 0-3, rank 1 days 4-6 and receives exactly one
+    block total (rank 0's); the union of their fields is the sequential chain."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (got[0]['first'], got[0]['count'], got[0]['prev']) == (0, 4, 0)
+    assert (got[1]['first'], got[1]['count'], got[1]['prev']) == (4, 3, 1)
+    assert got[0]['flagged'] is False and got[1]['flagged'] is False
+    rng = np.random.default_rng(5)
+    P, nd = 24, 7
+    A = np.zeros((P, P)); A[3, 4] = 1.0
+    fields = {**got[0]['fields'], **got[1]['fields']}
+    assert sorted(fields) == list(range(nd))
+    for d in range(nd):
+        k = np.zeros((P, P)); k[:3, :3] = rng.random((3, 3)); k /= k.sum()
+        A = np.fft.ifft2(np.fft.fft2(A) * np.fft.fft2(k)).real          # the sequential chain, day by day
+        np.testing.assert_allclose(fields[d], A, rtol=0, atol=1e-14)
+
+
+def test_split_days():
+    from parasitoids_amd import parallel
+    assert parallel.split_days(30, 8) == [(0, 4), (4, 4), (8, 4), (12, 4), (16, 4), (20, 4), (24, 3), (27, 3)]
+    assert parallel.split_days(5, 1) == [(0, 5)]
+    assert sum(c for _, c in parallel.split_days(17, 6)) == 17
