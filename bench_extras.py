@@ -622,6 +622,64 @@ def multi_gpu_record(rank, world, device=None, rehearse=False, members_per_rank=
                 'seconds': round(t_sh, 4), 'one_gpu_builds_all_days_s': round(t_one, 4),
                 'speedup': round(t_one / t_sh, 2), 'coo_entries': shards[0][1]['entries'],
                 'bytes_gathered_per_rank': shards[0][1]['entries'] * 16}
+    # ---- one flag-free simulation split over the ranks by days: the headline stack, every rank
+    # its block of days, ONE all-gather of a spectrum per rank in between -- next to the same chain run sequentially
+    # by every rank on its own.  (chain_prefix_split keeps its own collectives safe against a failing rank.)
+    del errors[:]
+    split = None
+    if not rehearse:
+        Rs, Ks, nds = 2048, 2049, 30
+
+        def split_setup():
+            from parasitoids_amd import hip_lib, synthetic
+            state, kernels, _ = synthetic.make_stack(R=Rs, K=Ks, ndays=nds, seed=20240613)
+            s = hip_lib.HipSolve(state, [Ks, Ks], mode='fast', chain_only=True, device=device)
+            s.set_kernels(kernels)
+            for _ in range(2):                       # the sequential chain, warm and hinted
+                s.set_state(state)
+                s.run_chain(renorm=True)
+            s.sync()
+            t0 = time.perf_counter()
+            s.set_state(state)
+            s.run_chain(renorm=True)
+            s.sync()
+            return s, state, time.perf_counter() - t0
+        setup = guarded('prefix split setup', split_setup, None)
+        if parallel.all_ok(setup is not None and world <= nds):
+            s_split, state_s, t_seq = setup
+
+            def split_run():
+                ops = parallel.DeviceBlockOps(s_split)
+                ts, blk = [], None
+                for rep in range(3):
+                    s_split.set_state(state_s)
+                    s_split.sync()
+                    barrier()
+                    t0 = time.perf_counter()
+                    blk = parallel.chain_prefix_split(ops, nds)
+                    s_split.sync()
+                    ts.append(time.perf_counter() - t0)
+                return {'split_s': min(ts[1:]), 'sequential_s': t_seq, 'first': blk[0], 'count': blk[1],
+                        'flagged': blk[2], 'fft_len': s_split.fft_len}
+            split = guarded('prefix split', split_run, None)
+        if setup is not None:
+            guarded('prefix split close', setup[0].close, None)
+    barrier()
+    splits = parallel.gather_objects((rank, split, list(errors)))
+    if rank == 0 and not rehearse:
+        if any(sp is None for _, sp, _ in splits):
+            out['prefix_split'] = {'error': [m for _, _, e in splits for m in e] or ['skipped: more ranks than days']}
+        else:
+            t_sp = max(sp['split_s'] for _, sp, _ in splits)
+            t_sq = max(sp['sequential_s'] for _, sp, _ in splits)
+            out['prefix_split'] = {
+                'workload': 'headline stack (N = %d, %d days, FFT %d): ONE simulation, rank g runs the g-th block of '
+                            'days, one all-gather of a %d-byte spectrum per rank in between'
+                            % (2 * Rs + 1, nds, splits[0][1]['fft_len'], 16 * splits[0][1]['fft_len'] * (((splits[0][1]['fft_len'] // 2 + 1) + 7) // 8 * 8)),
+                'seconds': round(t_sp, 5), 'sequential_chain_on_one_rank_s': round(t_sq, 5),
+                'speedup': round(t_sq / t_sp, 3), 'grid_days_per_s': round(nds / t_sp, 1),
+                'blocks': [(sp['first'], sp['count']) for _, sp, _ in sorted(splits)],
+                'flagged': bool(any(sp['flagged'] for _, sp, _ in splits))}
     # ---- config 4
     seed = 1000 + rank
     del errors[:]

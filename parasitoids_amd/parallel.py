@@ -338,6 +338,19 @@ class DeviceBlockOps:
         return self.s.block_finish(first, count, [t.data_ptr() for t in prev], self.negval, self.scale, self.renorm)
 
 
+def all_ok(ok):
+    """True on every rank iff `ok` was true on every rank (one tiny all-reduce): what a rank asks before it enters
+    a collective that a failed rank would never reach."""
+    import torch
+    dist = _dist()
+    rank, world = rank_world()
+    if world == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def chain_prefix_split(ops, nd):
     """ONE simulation's flag-free day chain over the ranks (no counterpart in the reference,
     whose CalcSol.py:140-201 loop is sequential): rank g owns the g-th contiguous block of the nd days.
@@ -353,7 +366,16 @@ def chain_prefix_split(ops, nd):
     if nd < world:
         raise ValueError('chain_prefix_split: %d days for %d ranks' % (nd, world))
     first, count = split_days(nd, world)[rank]
-    total = ops.prefix(first, count)
+    # a rank whose own work fails still takes part in every collective up to the point where all ranks know
+    # (all_ok) and raise together -- nobody is left waiting in the all-gather
+    err, total = None, None
+    try:
+        total = ops.prefix(first, count)
+    except Exception as e:
+        err = e
+    if not all_ok(err is None):
+        raise RuntimeError('chain_prefix_split: the block products failed on a rank%s'
+                           % ('' if err is None else ' (this one: %s: %s)' % (type(err).__name__, err)))
     if world > 1:
         via_host = total.is_cuda and dist.get_backend() != 'nccl'      # gloo rehearsal: no device collectives
         w = total.cpu() if via_host else total
@@ -362,11 +384,16 @@ def chain_prefix_split(ops, nd):
         prev = [o.to(total.device) if via_host else o for o in outs[:rank]]
     else:
         prev = []
-    flagged = bool(ops.finish(first, count, prev))
+    flagged = True
+    try:
+        flagged = bool(ops.finish(first, count, prev))
+    except Exception as e:
+        err = e
+    if not all_ok(err is None):
+        raise RuntimeError('chain_prefix_split: the block records failed on a rank%s'
+                           % ('' if err is None else ' (this one: %s: %s)' % (type(err).__name__, err)))
     if world > 1:
-        f = torch.tensor([int(flagged)], dtype=torch.int32)
-        if dist.get_backend() == 'nccl':
-            f = f.to(total.device)
+        f = torch.tensor([int(flagged)], dtype=torch.int32, device=_device())
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         flagged = bool(int(f.item()))
     return first, count, flagged

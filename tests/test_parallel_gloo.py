@@ -135,7 +135,7 @@ class _NumpyBlockOps:
         return False
 
 
-def _split_worker(rank, world, port, q):
+def _split_worker(rank, world, port, q, fail_rank=None):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       LOCAL_RANK=str(rank))
@@ -149,6 +149,17 @@ def _split_worker(rank, world, port, q):
     for _ in range(nd):
         k = np.zeros((P, P)); k[:3, :3] = rng.random((3, 3)); kernels.append(k / k.sum())
     ops = _NumpyBlockOps(state, kernels)
+    if fail_rank is not None:
+        if rank == fail_rank:
+            ops.prefix = lambda first, count: 1 / 0        # this rank's block products fail
+        try:
+            parallel.chain_prefix_split(ops, nd)
+            q.put((rank, 'no error'))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     first, count, flagged = parallel.chain_prefix_split(ops, nd)
     q.put((rank, dict(first=first, count=count, flagged=flagged, prev=ops.prev_seen, fields=ops.fields)))
     dist.barrier()
@@ -181,6 +192,23 @@ def test_prefix_split_exchange_two_ranks():
         k = np.zeros((P, P)); k[:3, :3] = rng.random((3, 3)); k /= k.sum()
         A = np.fft.ifft2(np.fft.fft2(A) * np.fft.fft2(k)).real          # the sequential chain, day by day
         np.testing.assert_allclose(fields[d], A, rtol=0, atol=1e-14)
+
+
+def test_prefix_split_failing_rank_raises_everywhere():
+    """A rank whose block products fail does not leave the others in the all-gather: every rank raises."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert 'failed on a rank' in got[0] and 'this one' not in got[0]
+    assert 'failed on a rank' in got[1] and 'ZeroDivisionError' in got[1]
 
 
 def test_split_days():
