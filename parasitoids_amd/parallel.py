@@ -382,6 +382,10 @@ def chain_prefix_split(ops, nd):
         outs = [torch.empty_like(w) for _ in range(world)]
         dist.all_gather(outs, w)
         prev = [o.to(total.device) if via_host else o for o in outs[:rank]]
+        if total.is_cuda:
+            # under "nccl" the call returns once the collective is ENQUEUED on torch's stream; the library reads
+            # the gathered totals on the solver's own stream, which knows nothing of that one
+            torch.cuda.synchronize()
     else:
         prev = []
     flagged = True
